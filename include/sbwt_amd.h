@@ -1,0 +1,143 @@
+/*
+ * sbwt_amd.h -- C ABI of the MI355X (gfx950) implementation of sBWT's read-mapping hot path.
+ *
+ * The upstream program exposes no plugin / FFI interface; the seam this library replaces is the
+ * per-read functor that Searcher::search hands to Job_distributer (src/aligner/searcher.hpp:346-372),
+ * which calls Searcher::start_sbwt_match (searcher.hpp:386-458) over the tables loaded by
+ * Searcher_impl::load_table (searcher.hpp:190-204).  Every entry point below cites the upstream
+ * interface it stands in for.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions: every function returns 0 (SBWT_OK) or a negative SBWT_ERR_* code; the message for
+ * the calling thread's last failure is sbwt_last_error().  Nothing throws or exits across the ABI.
+ * Calls on distinct sbwt_ctx objects may run concurrently (this mirrors the concurrent functor
+ * calls of the upstream thread pool); one sbwt_ctx serves one call at a time.
+ */
+#ifndef SBWT_AMD_H_
+#define SBWT_AMD_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBWT_OK 0
+#define SBWT_ERR_IO (-1)            /* file missing / unreadable / unwritable */
+#define SBWT_ERR_FORMAT (-2)        /* index files damaged (main.cpp:34-47,190-194) */
+#define SBWT_ERR_HIP (-3)           /* HIP runtime failure, or no gfx950 device */
+#define SBWT_ERR_ARG (-4)           /* bad argument */
+#define SBWT_ERR_ILLEGAL_CHAR (-5)  /* read with a byte outside ACGT: upstream throws "illegal char" (searcher.hpp:399) and aborts */
+#define SBWT_ERR_TOO_SHORT (-6)     /* read shorter than 12: upstream substr throws (searcher.hpp:404) and aborts */
+#define SBWT_ERR_CAPACITY (-7)      /* caller-provided output buffer too small */
+#define SBWT_ERR_NOMEM (-8)
+
+typedef struct sbwt_index sbwt_index; /* the loaded tables: Aligner_table<BWT_Aligner> (aligner_table.hpp:49-302) */
+typedef struct sbwt_ctx sbwt_ctx;     /* one stream + workspace: one worker of the upstream pool */
+
+/* One reported alignment, in upstream emission order (push_position, searcher.hpp:504-539). */
+typedef struct sbwt_hit {
+  uint64_t pos0;   /* 0-based position in the chromosome, N offset added back (SAM POS = pos0 + 1) */
+  uint32_t chr_id; /* index into the chromosome table (order of prefix.chrStart) */
+  uint32_t is_rc;  /* upstream isRC: 1 -> FLAG 0 / SEQ as read; 0 -> FLAG 16 / SEQ reverse-complemented */
+} sbwt_hit;
+
+/* Per-read result of start_sbwt_match (searcher.hpp:386-458). */
+typedef struct sbwt_read_result {
+  uint64_t sa_lo, sa_hi; /* SA interval after the backward search (searcher.hpp:404-410) */
+  uint64_t first_hit;    /* index of this read's first sbwt_hit in the hits buffer */
+  int32_t nh;            /* number of hits that survived the filters = upstream return value / NH */
+  uint32_t flags;        /* SBWT_RF_* */
+} sbwt_read_result;
+#define SBWT_RF_SUPPRESSED 1u /* raw interval larger than `limit` (searcher.hpp:415) */
+#define SBWT_RF_TRUNCATED 2u  /* more pushes than raw interval size: only possible on an index that violates the k-ordering contract */
+
+typedef struct sbwt_index_info {
+  uint64_t n;              /* number of suffixes = 2 * real_size + 1 */
+  uint64_t real_size;      /* Aligner_table::_realSize = sum of chrLen */
+  uint64_t interval;       /* Aligner_table::interval */
+  uint64_t first_location; /* SA index of text position 0 */
+  uint64_t n_chr, n_npos, n_loc;
+  uint64_t device_bytes;   /* HBM held by the device layout */
+  int device;
+} sbwt_index_info;
+
+const char *sbwt_last_error(void);
+/* Number of usable gfx950 devices; fails (does not fall back) when there is none. */
+int sbwt_device_count(int *count);
+
+/* ---- index ------------------------------------------------------------------------------- */
+
+/* Replaces Searcher_impl::load_table (searcher.hpp:190-204 -> Aligner_table::readTable / readNPosLen /
+ * readChrStartPos / readChrLen): reads prefix.{t_table.bwt,NposLen.z,chrStart,chrLen} in the on-disk
+ * format `sbwt build` writes and lays the tables out in the HBM of `device`. */
+int sbwt_index_load(const char *prefix, int device, sbwt_index **out);
+
+/* Same device layout from reference-format tables already in host memory (what readTable would have
+ * produced): used by the index builder and by callers that keep the tables themselves.
+ * c_function4 = c_function['A','C','G','T']; occ[c] has n/interval+1 entries; location_table is
+ * n_loc (i, SA[i]) pairs; chr_names may be NULL (names chr1..). */
+int sbwt_index_from_tables(int device, uint64_t interval, uint64_t n, uint64_t first_location,
+                           uint64_t real_size, const uint64_t *c_function4, const uint64_t *c_functions,
+                           const uint64_t *occA, const uint64_t *occC, const uint64_t *occG,
+                           const uint64_t *occT, const uint8_t *jbwt_seq, const uint8_t *fbwt,
+                           const uint64_t *location_table, uint64_t n_loc, uint64_t n_chr,
+                           const uint64_t *chr_start, const char *const *chr_names, uint64_t n_npos,
+                           const uint64_t *npos_key, const uint64_t *npos_val, sbwt_index **out);
+
+void sbwt_index_free(sbwt_index *ix);
+int sbwt_index_get_info(const sbwt_index *ix, sbwt_index_info *info);
+/* chromosome name i (Aligner_table::chr_start_pos values); NULL when out of range */
+const char *sbwt_index_chr_name(const sbwt_index *ix, uint64_t i);
+
+/* Replaces Indexer::build (indexer.hpp:137-229: Genome_pre_handler::run_handler, the suffix sort,
+ * Aligner_table::createAllTable and saveTable): FASTA -> prefix.{t_table.bwt,NposLen.z,chrStart,chrLen},
+ * suffix ordering on the GPU.  sort_len is accepted for CLI compatibility; the order produced is a
+ * full suffix order, which is a valid sort_len-order for every sort_len. */
+int sbwt_build_index(const char *fasta_path, const char *prefix, uint64_t sort_len, uint64_t interval, int device);
+
+/* ---- mapping ----------------------------------------------------------------------------- */
+
+/* One worker: a HIP stream plus scratch sized for batches of up to max_reads reads. */
+int sbwt_ctx_create(const sbwt_index *ix, uint64_t max_reads, sbwt_ctx **out);
+void sbwt_ctx_free(sbwt_ctx *ctx);
+
+/* Read encoding.  Base j of read r is the 2-bit code (A=0,C=1,G=2,T=3) at bits [2*(j%16), 2*(j%16)+1]
+ * of 32-bit word  r*words_per_read + j/16 ; words_per_read is a multiple of 4 (16-byte records).
+ * sbwt_pack_reads packs ASCII reads (concatenated, offsets[n_reads+1]) and reports the first read the
+ * upstream program would have aborted on (bad_read, SBWT_ERR_ILLEGAL_CHAR / SBWT_ERR_TOO_SHORT). */
+uint32_t sbwt_words_per_read(uint32_t max_len);
+int sbwt_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t n_reads, uint32_t words_per_read,
+                    uint32_t *packed, uint32_t *lens, uint64_t *bad_read);
+
+/* Replaces the body of the functor at searcher.hpp:348-352 (start_sbwt_match, searcher.hpp:386-458:
+ * reverse complement, 12-mer init :83-96, backward search :102-105, suppression :415, level-0 locate
+ * :424-443, find_possible :460-503, push_position :504-539) for a whole batch.  All pointers are DEVICE
+ * pointers on the index's device; nothing is copied to or from the host.  results[n_reads],
+ * hits[hits_cap]; *n_hits_host (host pointer, may be NULL) receives the number of hits written.
+ * limit / strand are `sbwt map -m / -s` (main.cpp:167-168).  Hits of one read are contiguous and in
+ * upstream emission order; reads appear in hits[] in no particular order (use first_hit). */
+int sbwt_map_batch_device(sbwt_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_lens, uint64_t n_reads,
+                          uint32_t words_per_read, int limit, int strand, sbwt_read_result *d_results,
+                          sbwt_hit *d_hits, uint64_t hits_cap, uint64_t *n_hits_host);
+
+/* Same with HOST buffers (pinned staging + async copies on the ctx stream). */
+int sbwt_map_batch(sbwt_ctx *ctx, const uint32_t *packed, const uint32_t *lens, uint64_t n_reads,
+                   uint32_t words_per_read, int limit, int strand, sbwt_read_result *results,
+                   sbwt_hit *hits, uint64_t hits_cap, uint64_t *n_hits);
+
+/* Milliseconds the kernels of the last sbwt_map_batch* call on this ctx took, measured with HIP events
+ * on the ctx stream: [0] whole device pass, [1] search+unique-locate kernel, [2] multi-hit locate. */
+int sbwt_ctx_last_timing(const sbwt_ctx *ctx, float ms[3]);
+/* raw hipStream_t of the ctx, for callers that want to order their own work after a batch */
+void *sbwt_ctx_stream(const sbwt_ctx *ctx);
+
+/* Replaces Searcher::search (searcher.hpp:336-373) + Job_distributer<M_T>::distribute_jobs
+ * (job_distributer.hpp:37-90): FASTQ file -> SAM file ("stdout"/"-" = standard output), records in
+ * input order.  stats = {total reads, mapped, single, multi, SAM records} (searcher.hpp:353-370).
+ * n_threads = host threads for parsing / SAM formatting (`sbwt map -n`). */
+int sbwt_map_fastq(const sbwt_index *ix, const char *fastq_path, const char *sam_path, int limit, int strand,
+                   int n_threads, uint64_t stats[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""sbwt_amd -- MI355X (gfx950) implementation of sBWT's read-mapping hot path.
+
+Thin ctypes binding of the C ABI declared in include/sbwt_amd.h.  The library has no CPU
+fallback: every call that needs the GPU fails loudly when libsbwt_amd.so or a gfx950 device
+is missing.
+"""
+from .api import (  # noqa: F401
+    SbwtError, Index, Context, Hit, ReadResult, lib, lib_path, pack_reads, words_per_read,
+    device_count, build_index, RF_SUPPRESSED, RF_TRUNCATED,
+)

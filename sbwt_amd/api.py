@@ -1,0 +1,224 @@
+"""ctypes binding of include/sbwt_amd.h (one Python wrapper per C entry point, same names)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RF_SUPPRESSED = 1
+RF_TRUNCATED = 2
+
+
+class SbwtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sbwt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Hit(C.Structure):
+    _fields_ = [("pos0", C.c_uint64), ("chr_id", C.c_uint32), ("is_rc", C.c_uint32)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("sa_lo", C.c_uint64), ("sa_hi", C.c_uint64), ("first_hit", C.c_uint64),
+                ("nh", C.c_int32), ("flags", C.c_uint32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("real_size", C.c_uint64), ("interval", C.c_uint64),
+                ("first_location", C.c_uint64), ("n_chr", C.c_uint64), ("n_npos", C.c_uint64),
+                ("n_loc", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int)]
+
+
+HIT_DTYPE = np.dtype([("pos0", "<u8"), ("chr_id", "<u4"), ("is_rc", "<u4")])
+RESULT_DTYPE = np.dtype([("sa_lo", "<u8"), ("sa_hi", "<u8"), ("first_hit", "<u8"), ("nh", "<i4"), ("flags", "<u4")])
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libsbwt_amd.so")
+
+
+def lib():
+    """Loads libsbwt_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SbwtError(-3, "%s is missing: run `python -m sbwt_amd.build` (hipcc, gfx950)" % path)
+    L = C.CDLL(path)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    p = C.POINTER
+    L.sbwt_last_error.restype = C.c_char_p
+    L.sbwt_device_count.argtypes = [p(C.c_int)]
+    L.sbwt_index_load.argtypes = [C.c_char_p, i32, p(vp)]
+    L.sbwt_index_from_tables.argtypes = [i32, u64, u64, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp,
+                                         vp, u64, vp, vp, p(vp)]
+    L.sbwt_index_free.argtypes = [vp]
+    L.sbwt_index_free.restype = None
+    L.sbwt_index_get_info.argtypes = [vp, p(IndexInfo)]
+    L.sbwt_index_chr_name.argtypes = [vp, u64]
+    L.sbwt_index_chr_name.restype = C.c_char_p
+    L.sbwt_build_index.argtypes = [C.c_char_p, C.c_char_p, u64, u64, i32]
+    L.sbwt_ctx_create.argtypes = [vp, u64, p(vp)]
+    L.sbwt_ctx_free.argtypes = [vp]
+    L.sbwt_ctx_free.restype = None
+    L.sbwt_words_per_read.argtypes = [u32]
+    L.sbwt_words_per_read.restype = u32
+    L.sbwt_pack_reads.argtypes = [vp, vp, u64, u32, vp, vp, p(u64)]
+    L.sbwt_map_batch_device.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
+    L.sbwt_map_batch.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
+    L.sbwt_ctx_last_timing.argtypes = [vp, p(C.c_float * 3)]
+    L.sbwt_ctx_stream.argtypes = [vp]
+    L.sbwt_ctx_stream.restype = vp
+    L.sbwt_map_fastq.argtypes = [vp, C.c_char_p, C.c_char_p, i32, i32, i32, p(u64 * 5)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SbwtError(rc, lib().sbwt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().sbwt_device_count(C.byref(n)))
+    return n.value
+
+
+def words_per_read(max_len):
+    return int(lib().sbwt_words_per_read(int(max_len)))
+
+
+def pack_reads(reads, wpr=None):
+    """reads: list of ASCII strings/bytes -> (packed uint32 [n, wpr], lens uint32 [n])."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    if wpr is None:
+        wpr = words_per_read(max((len(b) for b in bs), default=1))
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    seqs = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
+    packed = np.zeros((len(bs), wpr), dtype=np.uint32)
+    lens = np.zeros(len(bs), dtype=np.uint32)
+    bad = C.c_uint64(0)
+    _check(lib().sbwt_pack_reads(seqs.ctypes.data, offsets.ctypes.data, len(bs), wpr, packed.ctypes.data,
+                                 lens.ctypes.data, C.byref(bad)))
+    return packed, lens
+
+
+def build_index(fasta, prefix, sort_len=256, interval=64, device=0):
+    _check(lib().sbwt_build_index(os.fsencode(fasta), os.fsencode(prefix), sort_len, interval, device))
+
+
+class Index:
+    """sbwt_index handle (Aligner_table<BWT_Aligner> resident in HBM)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load(cls, prefix, device=0):
+        h = C.c_void_p()
+        _check(lib().sbwt_index_load(os.fsencode(prefix), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_tables(cls, device, interval, n, first_location, real_size, c_function4, c_functions, occ, jbwt_seq,
+                    fbwt, location_table, chr_start, npos_key, npos_val, chr_names=None):
+        def a(x, dt):
+            return np.ascontiguousarray(x, dtype=dt)
+        c4 = a(c_function4, np.uint64); cfs = a(c_functions, np.uint64)
+        occs = [a(o, np.uint64) for o in occ]
+        jb = a(jbwt_seq, np.uint8); fb = a(fbwt, np.uint8); loc = a(location_table, np.uint64)
+        cs = a(chr_start, np.uint64); nk = a(npos_key, np.uint64); nv = a(npos_val, np.uint64)
+        names = None
+        if chr_names is not None:
+            arr = (C.c_char_p * len(chr_names))(*[s.encode() for s in chr_names])
+            names = C.cast(arr, C.c_void_p)
+        h = C.c_void_p()
+        _check(lib().sbwt_index_from_tables(device, interval, n, first_location, real_size, c4.ctypes.data,
+                                            cfs.ctypes.data, occs[0].ctypes.data, occs[1].ctypes.data,
+                                            occs[2].ctypes.data, occs[3].ctypes.data, jb.ctypes.data, fb.ctypes.data,
+                                            loc.ctypes.data, loc.size // 2, cs.size, cs.ctypes.data, names, nk.size,
+                                            nk.ctypes.data, nv.ctypes.data, C.byref(h)))
+        return cls(h)
+
+    def info(self):
+        i = IndexInfo()
+        _check(lib().sbwt_index_get_info(self._h, C.byref(i)))
+        return i
+
+    def chr_names(self):
+        return [lib().sbwt_index_chr_name(self._h, k).decode() for k in range(self.info().n_chr)]
+
+    def map_fastq(self, fastq, sam, limit=1000, strand=2, n_threads=1):
+        st = (C.c_uint64 * 5)()
+        _check(lib().sbwt_map_fastq(self._h, os.fsencode(fastq), os.fsencode(sam), limit, strand, n_threads,
+                                    C.byref(st)))
+        return list(st)
+
+    def close(self):
+        if self._h:
+            lib().sbwt_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """sbwt_ctx handle: one stream + workspace."""
+
+    def __init__(self, index, max_reads):
+        self.index = index
+        self._h = C.c_void_p()
+        _check(lib().sbwt_ctx_create(index._h, int(max_reads), C.byref(self._h)))
+
+    def map_batch(self, packed, lens, limit=1000, strand=2, hits_cap=None):
+        """Host-buffer entry point. Returns (results structured array, hits structured array)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = lens.size
+        wpr = packed.shape[1] if packed.ndim == 2 else packed.size // max(n, 1)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        cap = int(hits_cap if hits_cap is not None else max(2 * n, 1024))
+        while True:
+            hits = np.zeros(cap, dtype=HIT_DTYPE)
+            nh = C.c_uint64(0)
+            rc = lib().sbwt_map_batch(self._h, packed.ctypes.data, lens.ctypes.data, n, wpr, limit, strand,
+                                      res.ctypes.data, hits.ctypes.data, cap, C.byref(nh))
+            if rc == -7 and hits_cap is None:
+                cap = int(nh.value) + 16
+                continue
+            _check(rc)
+            return res, hits[: nh.value]
+
+    def map_batch_device(self, d_packed, d_lens, n_reads, wpr, d_results, d_hits, hits_cap, limit=1000, strand=2):
+        """Device-pointer entry point (integers are raw device addresses)."""
+        nh = C.c_uint64(0)
+        _check(lib().sbwt_map_batch_device(self._h, d_packed, d_lens, n_reads, wpr, limit, strand, d_results, d_hits,
+                                           hits_cap, C.byref(nh)))
+        return nh.value
+
+    def last_timing(self):
+        ms = (C.c_float * 3)()
+        _check(lib().sbwt_ctx_last_timing(self._h, C.byref(ms)))
+        return list(ms)
+
+    def close(self):
+        if self._h:
+            lib().sbwt_ctx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,387 @@
+// device_index.hip -- load-time re-layout of the reference-format tables into the HBM layout of
+// device_layout.h.  One-time work per index; correctness first, all kernels are plain gfx950 HIP.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "index_impl.hpp"
+#include "rank_device.h"
+
+namespace sbwt {
+
+constexpr int kChunk = 256;  // index blocks per scan chunk = threads per workgroup
+
+struct LayoutErrors {
+  unsigned long long loc_fbwt_mismatch;  // location_table key whose fbwt is not 0, or the converse
+  unsigned long long loc_not_sorted;
+  unsigned long long occ_mismatch;       // occ_function checkpoint differs from the BWT it summarises
+};
+
+// ---- blocks1: planes + sampled bitmap ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_planes1(Block1* __restrict__ blocks, uint64_t n_blocks, uint64_t n,
+                                                 const uint8_t* __restrict__ jbwt, uint64_t jbwt_len,
+                                                 const uint8_t* __restrict__ fbwt, const uint64_t* __restrict__ loc,
+                                                 uint64_t n_loc, LayoutErrors* err) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  uint64_t plo = 0, phi = 0;
+  for (int k = 0; k < 16; ++k) {
+    const uint64_t byte_idx = b * 16 + k;
+    const uint32_t byte = byte_idx < jbwt_len ? jbwt[byte_idx] : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // base q of a byte sits at bits 7-2q .. 6-2q (jbit.hpp:193-206)
+      const uint32_t code = (byte >> (6 - 2 * q)) & 3u;
+      const int j = 4 * k + q;
+      plo |= (uint64_t)(code & 1u) << j;
+      phi |= (uint64_t)(code >> 1) << j;
+    }
+  }
+  // sampled bitmap: position i is sampled iff fbwt[i] == 0 and i is a key of location_table
+  const uint64_t p0 = b * 64;
+  uint64_t l = 0, h = n_loc;
+  while (l < h) {
+    const uint64_t m = (l + h) >> 1;
+    if (loc[2 * m] < p0) l = m + 1; else h = m;
+  }
+  uint64_t sampled = 0;
+  unsigned long long bad = 0;
+  for (uint64_t k = l; k < n_loc; ++k) {
+    const uint64_t i = loc[2 * k];
+    if (i >= p0 + 64) break;
+    if (i < n && fbwt[i] == 0) sampled |= 1ull << (i - p0); else ++bad;
+  }
+  uint64_t zeros = 0;
+  for (int j = 0; j < 64; ++j)
+    if (p0 + j < n && fbwt[p0 + j] == 0) zeros |= 1ull << j;
+  if (zeros != sampled) bad += (unsigned long long)__popcll(zeros ^ sampled);
+  if (bad) atomicAdd(&err->loc_fbwt_mismatch, bad);
+  Block1 out;
+  out.cnt[0] = out.cnt[1] = out.cnt[2] = out.cnt[3] = 0;
+  out.plane_lo = plo;
+  out.plane_hi = phi;
+  out.sampled = sampled;
+  out.sampled_base = l;
+  blocks[b] = out;
+}
+
+__global__ __launch_bounds__(256) void k_loc_vals(const uint64_t* __restrict__ loc, uint64_t n_loc, uint64_t n,
+                                                  uint64_t* __restrict__ loc_vals, LayoutErrors* err) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_loc) return;
+  loc_vals[k] = loc[2 * k + 1];
+  if (loc[2 * k] >= n || (k + 1 < n_loc && loc[2 * k] >= loc[2 * k + 2])) atomicAdd(&err->loc_not_sorted, 1ull);
+}
+
+// ---- chunked exclusive scan of K per-block counters ------------------------------------------
+// exclusive scan of one u32 per thread over a 256-thread workgroup; returns the exclusive prefix and
+// leaves the workgroup total in *total.  lds must hold 4 u32 and be distinct per concurrent call site.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t s = lds[w];
+    if (w < wave) wave_off += s;
+    tot += s;
+  }
+  *total = tot;
+  return wave_off + inc - v;
+}
+
+template <int K>
+struct Counts { uint32_t c[K]; };
+
+__device__ __forceinline__ Counts<4> counts_of(const Block1& b) {
+  Counts<4> r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) r.c[c] = (uint32_t)__popcll(match1(b.plane_lo, b.plane_hi, (uint32_t)c));
+  return r;
+}
+__device__ __forceinline__ uint64_t match2(const uint64_t* plane, uint32_t code) {
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m &= ((code >> k) & 1u) ? plane[k] : ~plane[k];
+  return m;
+}
+__device__ __forceinline__ Counts<16> counts_of(const Block2& b) {
+  Counts<16> r;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) r.c[c] = (uint32_t)__popcll(match2(b.plane, (uint32_t)c));
+  return r;
+}
+
+// totals[chunk][K] = counts of one chunk of 256 blocks
+template <int K, typename B>
+__global__ __launch_bounds__(256) void k_chunk_totals(const B* __restrict__ blocks, uint64_t n_blocks,
+                                                      uint64_t* __restrict__ totals) {
+  __shared__ uint32_t lds[4];
+  const uint64_t b = (uint64_t)blockIdx.x * kChunk + threadIdx.x;
+  Counts<K> cnt;
+  if (b < n_blocks) cnt = counts_of(blocks[b]);
+  else
+    for (int k = 0; k < K; ++k) cnt.c[k] = 0;
+  for (int k = 0; k < K; ++k) {
+    uint32_t tot;
+    block_excl_scan(cnt.c[k], lds, &tot);
+    if (threadIdx.x == 0) totals[(uint64_t)blockIdx.x * K + k] = tot;
+    __syncthreads();
+  }
+}
+
+// in place: totals[chunk][k] becomes the exclusive prefix over chunks (one thread per counter)
+__global__ void k_scan_chunks(uint64_t* totals, uint64_t n_chunks, int K) {
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  uint64_t acc = 0;
+  for (uint64_t c = 0; c < n_chunks; ++c) {
+    const uint64_t t = totals[c * K + k];
+    totals[c * K + k] = acc;
+    acc += t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_apply1(Block1* __restrict__ blocks, uint64_t n_blocks,
+                                                const uint64_t* __restrict__ chunk_base, uint64_t c0, uint64_t c1,
+                                                uint64_t c2, uint64_t c3, uint64_t interval, const uint64_t* occA,
+                                                const uint64_t* occC, const uint64_t* occG, const uint64_t* occT,
+                                                uint64_t occ_len, LayoutErrors* err) {
+  __shared__ uint32_t lds[4];
+  const uint64_t b = (uint64_t)blockIdx.x * kChunk + threadIdx.x;
+  const bool live = b < n_blocks;
+  Counts<4> cnt;
+  if (live) cnt = counts_of(blocks[b]);
+  else
+    for (int k = 0; k < 4; ++k) cnt.c[k] = 0;
+  const uint64_t C[4] = {c0, c1, c2, c3};
+  const uint64_t* occ[4] = {occA, occC, occG, occT};
+  for (int k = 0; k < 4; ++k) {
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(cnt.c[k], lds, &tot);
+    __syncthreads();
+    if (!live) continue;
+    const uint64_t raw = chunk_base[(uint64_t)blockIdx.x * 4 + k] + ex;  // #k in bwt[0 .. 64b), '$' as 'A'
+    blocks[b].cnt[k] = C[k] + raw;
+    // the file's own checkpoints must agree with the BWT they summarise (same values the upstream rank reads)
+    const uint64_t pos = b * 64;
+    if (occ[k] && pos % interval == 0 && pos / interval < occ_len && occ[k][pos / interval] != raw)
+      atomicAdd(&err->occ_mismatch, 1ull);
+  }
+}
+
+// ---- sa_full: memoised unique-hit locate ---------------------------------------------------------
+// sa_full[i] = what the upstream locate reports for the interval [i, i+1): level-0 test
+// (searcher.hpp:424-443) then find_possible (searcher.hpp:460-503) on a size-1 interval, i.e. follow LF
+// until a sampled position; kNoPosition if depth `interval` or the '$' row is reached first.
+__global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __restrict__ sa_full) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ix.n) return;
+  uint64_t cur = i, t = 0, res = kNoPosition;
+  for (;;) {
+    const Block1* b = ix.blocks1 + (cur >> 6);
+    const uint4 pl = *reinterpret_cast<const uint4*>(&b->plane_lo);
+    const uint4 sm = *reinterpret_cast<const uint4*>(&b->sampled);
+    const uint32_t o = (uint32_t)(cur & 63);
+    const uint64_t sampled = ((uint64_t)sm.y << 32) | sm.x, base = ((uint64_t)sm.w << 32) | sm.z;
+    if ((sampled >> o) & 1ull) {
+      res = ix.loc_vals[base + (uint64_t)__popcll(sampled & below(o))] + t;
+      break;
+    }
+    if (t + 1 >= ix.interval) break;      // find_possible: len >= interval
+    if (cur == ix.first_location) break;  // '$' row: every child interval is empty
+    const uint64_t plo = ((uint64_t)pl.y << 32) | pl.x, phi = ((uint64_t)pl.w << 32) | pl.z;
+    const uint32_t c = (uint32_t)((plo >> o) & 1ull) | ((uint32_t)((phi >> o) & 1ull) << 1);
+    uint64_t r = b->cnt[c] + (uint64_t)__popcll(match1(plo, phi, c) & below(o));
+    if (c == 0 && cur > ix.first_location) r -= 1;
+    cur = r;
+    ++t;
+  }
+  sa_full[i] = res;
+}
+
+// ---- blocks2: two-step planes ----------------------------------------------------------------------
+// one wave per index block; lane j owns position 64b + j
+__global__ __launch_bounds__(256) void k_planes2(DeviceIndex ix, Block2* __restrict__ blocks2, uint64_t* special) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t b = gid >> 6;
+  if (b >= ix.n_blocks) return;  // wave-uniform
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t j = b * 64 + lane;
+  const Block1* blk = ix.blocks1 + b;
+  uint32_t code = 0;
+  if (j < ix.n && j != ix.first_location) {
+    const uint32_t x = (uint32_t)((blk->plane_lo >> lane) & 1ull) | ((uint32_t)((blk->plane_hi >> lane) & 1ull) << 1);
+    const uint64_t j1 = lf1(ix, j, x);
+    uint32_t y = 0;
+    if (j1 == ix.first_location) {
+      special[0] = j;       // the one position whose second base is '$'
+      special[1] = 4 * x;   // stored with y = 0; rank2 takes it back out
+    } else {
+      const Block1* b1 = ix.blocks1 + (j1 >> 6);
+      const uint32_t o1 = (uint32_t)(j1 & 63);
+      y = (uint32_t)((b1->plane_lo >> o1) & 1ull) | ((uint32_t)((b1->plane_hi >> o1) & 1ull) << 1);
+    }
+    code = 4 * x + y;
+  }
+  uint64_t planes[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) planes[k] = __ballot((code >> k) & 1u);
+  if (lane == 0) {
+    Block2* o = blocks2 + b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o->plane[k] = planes[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o->reserved[k] = 0;
+  }
+}
+
+__global__ void k_k2(DeviceIndex ix, uint64_t* k2) {
+  const uint32_t code = threadIdx.x;
+  if (code >= 16) return;
+  const uint32_t x = code >> 2, y = code & 3;
+  // C[y] + Occ(y, C[x]): where the suffixes starting with y x begin
+  k2[code] = lf1(ix, ix.c_function[x], y);
+}
+
+__global__ __launch_bounds__(256) void k_apply2(Block2* __restrict__ blocks, uint64_t n_blocks,
+                                                const uint64_t* __restrict__ chunk_base, const uint64_t* __restrict__ k2,
+                                                uint64_t* __restrict__ sb_abs) {
+  __shared__ uint32_t lds[4];
+  const uint64_t b = (uint64_t)blockIdx.x * kChunk + threadIdx.x;
+  const bool live = b < n_blocks;
+  Counts<16> cnt;
+  if (live) cnt = counts_of(blocks[b]);
+  else
+    for (int k = 0; k < 16; ++k) cnt.c[k] = 0;
+  // superblock of this chunk: 2^31 positions = 2^25 blocks = 2^17 chunks (chunks never straddle one)
+  const uint64_t sb = ((uint64_t)blockIdx.x * kChunk) >> (kSuperShift - 6);
+  const uint64_t sb_chunk = sb << (kSuperShift - 6 - 8);
+  for (int k = 0; k < 16; ++k) {
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(cnt.c[k], lds, &tot);
+    __syncthreads();
+    const uint64_t base = chunk_base[(uint64_t)blockIdx.x * 16 + k], sbase = chunk_base[sb_chunk * 16 + k];
+    if (live) blocks[b].cnt[k] = (uint32_t)(base - sbase + ex);
+    if (blockIdx.x == sb_chunk && threadIdx.x == 0) sb_abs[sb * 16 + k] = k2[k] + sbase;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static inline uint32_t grid_for(uint64_t items, uint32_t per_block) { return (uint32_t)((items + per_block - 1) / per_block); }
+
+int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
+  DeviceIndex& d = ix->d;
+  d.n = raw.n;
+  d.first_location = raw.first_location;
+  d.real_size = raw.real_size;
+  d.interval = raw.interval;
+  d.n_blocks = raw.n / 64 + 1;
+  for (int c = 0; c < 4; ++c) d.c_function[c] = raw.c_function4[c];
+  d.c_functions = raw.c_functions;
+  d.special_pos[0] = raw.first_location;
+  d.special_code[0] = 0;
+  d.special_pos[1] = ~0ull;
+  d.special_code[1] = 0;
+  ix->n_loc = raw.n_loc;
+
+  const uint64_t nb = d.n_blocks;
+  const uint64_t n_chunks = (nb + kChunk - 1) / kChunk;
+  Block1* blocks1 = nullptr;
+  Block2* blocks2 = nullptr;
+  uint64_t *loc_vals = nullptr, *sa_full = nullptr, *sb_abs = nullptr;
+  if (int rc = dev_alloc(ix, &blocks1, nb)) return rc;
+  if (int rc = dev_alloc(ix, &loc_vals, raw.n_loc)) return rc;
+  if (int rc = dev_alloc(ix, &sa_full, raw.n)) return rc;
+  if (int rc = dev_alloc(ix, &blocks2, nb)) return rc;
+  const uint64_t n_super = ((nb - 1) >> (kSuperShift - 6)) + 1;
+  if (int rc = dev_alloc(ix, &sb_abs, n_super * 16)) return rc;
+
+  // temporaries
+  uint64_t* chunk_base = nullptr;
+  LayoutErrors* d_err = nullptr;
+  uint64_t* d_small = nullptr;  // [0..1] special, [2..17] k2
+  SBWT_HIP(hipMalloc(&chunk_base, n_chunks * 16 * sizeof(uint64_t)));
+  SBWT_HIP(hipMalloc(&d_err, sizeof(LayoutErrors)));
+  SBWT_HIP(hipMalloc(&d_small, 18 * sizeof(uint64_t)));
+  SBWT_HIP(hipMemset(d_err, 0, sizeof(LayoutErrors)));
+  SBWT_HIP(hipMemset(d_small, 0xff, 2 * sizeof(uint64_t)));
+
+  k_planes1<<<grid_for(nb, 256), 256>>>(blocks1, nb, raw.n, raw.jbwt, raw.n / 4 + 1, raw.fbwt, raw.loc, raw.n_loc, d_err);
+  if (raw.n_loc) k_loc_vals<<<grid_for(raw.n_loc, 256), 256>>>(raw.loc, raw.n_loc, raw.n, loc_vals, d_err);
+  k_chunk_totals<4, Block1><<<(uint32_t)n_chunks, kChunk>>>(blocks1, nb, chunk_base);
+  k_scan_chunks<<<1, 64>>>(chunk_base, n_chunks, 4);
+  k_apply1<<<(uint32_t)n_chunks, kChunk>>>(blocks1, nb, chunk_base, d.c_function[0], d.c_function[1], d.c_function[2],
+                                           d.c_function[3], raw.interval, raw.occ[0], raw.occ[1], raw.occ[2],
+                                           raw.occ[3], raw.occ_len, d_err);
+  SBWT_HIP(hipGetLastError());
+  d.blocks1 = blocks1;
+  d.loc_vals = loc_vals;
+
+  LayoutErrors h_err;
+  SBWT_HIP(hipMemcpy(&h_err, d_err, sizeof h_err, hipMemcpyDeviceToHost));
+  if (h_err.loc_fbwt_mismatch || h_err.loc_not_sorted || h_err.occ_mismatch) {
+    char msg[256];
+    snprintf(msg, sizeof msg,
+             "index tables are inconsistent (location_table/fbwt mismatches %llu, unsorted keys %llu, "
+             "occ_function mismatches %llu): index files appear to be damaged",
+             h_err.loc_fbwt_mismatch, h_err.loc_not_sorted, h_err.occ_mismatch);
+    set_error(msg);
+    hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
+    return -2;  // SBWT_ERR_FORMAT
+  }
+
+  k_sa_full<<<grid_for(raw.n, 256), 256>>>(d, sa_full);
+  d.sa_full = sa_full;
+
+  k_planes2<<<grid_for(nb * 64, 256), 256>>>(d, blocks2, d_small);
+  k_k2<<<1, 64>>>(d, d_small + 2);
+  k_chunk_totals<16, Block2><<<(uint32_t)n_chunks, kChunk>>>(blocks2, nb, chunk_base);
+  k_scan_chunks<<<1, 64>>>(chunk_base, n_chunks, 16);
+  k_apply2<<<(uint32_t)n_chunks, kChunk>>>(blocks2, nb, chunk_base, d_small + 2, sb_abs);
+  SBWT_HIP(hipGetLastError());
+  uint64_t h_small[2];
+  SBWT_HIP(hipMemcpy(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost));
+  d.special_pos[1] = h_small[0];
+  d.special_code[1] = h_small[0] == ~0ull ? 0u : (uint32_t)h_small[1];
+  d.blocks2 = blocks2;
+  d.sb_abs = sb_abs;
+  SBWT_HIP(hipDeviceSynchronize());
+  hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
+  return 0;
+}
+
+int upload_chr_tables(sbwt_index* ix) {
+  const ChrTables& t = ix->chr;
+  uint64_t *cs = nullptr, *nk = nullptr, *nv = nullptr;
+  if (int rc = dev_alloc(ix, &cs, t.start.size())) return rc;
+  if (int rc = dev_alloc(ix, &nk, t.npos_key.size())) return rc;
+  if (int rc = dev_alloc(ix, &nv, t.npos_val.size())) return rc;
+  SBWT_HIP(hipMemcpy(cs, t.start.data(), t.start.size() * 8, hipMemcpyHostToDevice));
+  SBWT_HIP(hipMemcpy(nk, t.npos_key.data(), t.npos_key.size() * 8, hipMemcpyHostToDevice));
+  SBWT_HIP(hipMemcpy(nv, t.npos_val.data(), t.npos_val.size() * 8, hipMemcpyHostToDevice));
+  ix->d.chr_start = cs;
+  ix->d.n_chr = (uint32_t)t.start.size();
+  ix->d.npos_key = nk;
+  ix->d.npos_val = nv;
+  ix->d.n_npos = (uint32_t)t.npos_key.size();
+  return 0;
+}
+
+}  // namespace sbwt
+
+sbwt_index::~sbwt_index() {
+  int cur = 0;
+  if (hipGetDevice(&cur) == hipSuccess) {
+    hipSetDevice(device);
+    for (void* p : allocs) hipFree(p);
+    hipSetDevice(cur);
+  }
+}

@@ -1,0 +1,65 @@
+// device_layout.h -- HBM layout of the FM-index used by the gfx950 kernels.
+//
+// The on-disk format (prefix.t_table.bwt) is untouched; at load time the tables of
+// Aligner_table<BWT_Aligner> (aligner_table.hpp:98-161) are re-laid so that ONE random HBM access
+// answers one (or two) rank steps.  Measured on MI355X (tools/gather_bench.hip): dependent random
+// gathers run at ~48 G accesses/s for any granule of 16..128 bytes as long as one wave instruction
+// touches few distinct lines, i.e. the walk is bound by the random-access (row-activate) rate, not
+// by bytes, up to 128 B per access.  So each access is made to do as much as 128 bytes allow.
+#pragma once
+#include <stdint.h>
+
+namespace sbwt {
+
+constexpr int kKmer = 12;                           // searcher.hpp:299 c_functions_interval
+constexpr uint64_t kNumKmer = 1ull << (2 * kKmer);  // 4^12
+
+// 64-byte block: 64 BWT positions, single-base rank (get_occ_using_jbwt) in one access.
+// Used for the odd step of the search, the multi-hit DFS (find_possible) and the load-time walks.
+struct alignas(64) Block1 {
+  uint64_t cnt[4];   // C[c] + #c in bwt[0 .. 64b), '$' counted as 'A' exactly as occ_function does
+  uint64_t plane_lo; // bit j = low bit of the 2-bit code of bwt[64b + j]
+  uint64_t plane_hi; // bit j = high bit
+  uint64_t sampled;  // bit j = fbwt[64b+j] == 0 and (64b+j) is a key of location_table
+  uint64_t sampled_base; // number of sampled positions before this block = index into loc_vals
+};
+static_assert(sizeof(Block1) == 64, "Block1 is one 64-byte granule");
+
+// 128-byte block: 64 BWT positions, TWO backward-search steps in one access.
+// code(j) = 4 * x + y,  x = bwt[j] (first prepended base), y = bwt[LF(j)] (second prepended base).
+// rank2(code, i) = sb_abs[i >> kSuperShift][code] + cnt[code] + popcount(match(code) & below(i & 63))
+// and  C[y] + Occ(y, C[x] + Occ(x, i)) == rank2(4x+y, i)  holds arithmetically for any table content
+// (LF restricted to the x-positions is an order-preserving bijection onto [C[x], C[x+1]) by definition).
+struct alignas(128) Block2 {
+  uint64_t plane[4];  // plane[k] bit j = bit k of code(64b + j)   (k = 0,1: y ; k = 2,3: x)
+  uint32_t cnt[16];   // #code in bwt2[superblock start .. 64b)
+  uint64_t reserved[4];
+};
+static_assert(sizeof(Block2) == 128, "Block2 is one 128-byte granule");
+constexpr int kSuperShift = 31;  // superblock = 2^31 positions, so relative counts fit 32 bits
+
+constexpr uint64_t kNoPosition = ~0ull;  // sa_full sentinel: the upstream unique-hit walk reports nothing
+
+// Everything the kernels need, passed by value.
+struct DeviceIndex {
+  uint64_t n;               // number of suffixes
+  uint64_t first_location;  // SA index whose BWT char is '$' (stored as 'A')
+  uint64_t real_size;       // Aligner_table::_realSize
+  uint64_t interval;        // DFS depth limit and SA sampling distance
+  uint64_t n_blocks;        // blocks cover positions 0 .. n (inclusive), = n/64 + 1
+  // the two positions of the 2-mer BWT whose code is undefined because one base is '$'
+  uint64_t special_pos[2];  // [0] = first_location (x = '$'), [1] = position whose LF is first_location (y = '$'), or ~0
+  uint32_t special_code[2]; // code stored there; rank2 subtracts it back out
+  uint64_t c_function[4];   // C['A'], C['C'], C['G'], C['T']
+  const uint64_t* c_functions;  // 4^12 + 1 entries, verbatim from the file
+  const Block1* blocks1;
+  const Block2* blocks2;
+  const uint64_t* sb_abs;   // [n_super][16]: K2[code] + #code before the superblock
+  const uint64_t* loc_vals; // SA value of the k-th sampled position (location_table[k].second)
+  const uint64_t* sa_full;  // memoised unique-hit locate: result of the upstream walk started at i
+  // push_position tables (searcher.hpp:504-539)
+  const uint64_t* chr_start; uint32_t n_chr;
+  const uint64_t* npos_key; const uint64_t* npos_val; uint32_t n_npos;
+};
+
+}  // namespace sbwt

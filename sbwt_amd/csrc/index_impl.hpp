@@ -1,0 +1,63 @@
+// index_impl.hpp -- the object behind the opaque `sbwt_index` handle, plus internal helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "device_layout.h"
+#include "index_file.hpp"
+
+namespace sbwt {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+#define SBWT_HIP(x)                                                     \
+  do {                                                                  \
+    hipError_t e__ = (x);                                               \
+    if (e__ != hipSuccess) return ::sbwt::hip_fail(e__, #x, __FILE__, __LINE__); \
+  } while (0)
+
+// Reference-format tables resident on the device (temporary inputs of the re-layout).
+struct RawDeviceTables {
+  uint64_t interval = 0, n = 0, first_location = 0, real_size = 0;
+  uint64_t c_function4[4] = {0, 0, 0, 0};
+  const uint64_t* c_functions = nullptr;  // 4^12 + 1; ownership moves to the index when own_c_functions
+  const uint8_t* jbwt = nullptr;          // n/4 + 1 bytes
+  const uint8_t* fbwt = nullptr;          // n bytes
+  const uint64_t* occ[4] = {nullptr, nullptr, nullptr, nullptr};  // may be null: no consistency check
+  uint64_t occ_len = 0;
+  const uint64_t* loc = nullptr;  // n_loc pairs
+  uint64_t n_loc = 0;
+};
+
+}  // namespace sbwt
+
+struct sbwt_index {
+  int device = 0;
+  sbwt::DeviceIndex d{};
+  std::vector<void*> allocs;  // every hipMalloc the index owns
+  uint64_t device_bytes = 0;
+  sbwt::ChrTables chr;
+  uint64_t n_loc = 0;
+  ~sbwt_index();
+};
+
+namespace sbwt {
+// Builds blocks1 / loc_vals / sa_full / blocks2 / sb_abs from raw device tables.  `c_functions` is
+// adopted (not copied).  Runs on the current device, default stream, synchronous.
+int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw);
+int upload_chr_tables(sbwt_index* ix);
+template <typename T>
+int dev_alloc(sbwt_index* ix, T** p, uint64_t count) {
+  void* q = nullptr;
+  uint64_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  ix->allocs.push_back(q);
+  ix->device_bytes += bytes;
+  *p = static_cast<T*>(q);
+  return 0;
+}
+}  // namespace sbwt

@@ -1,0 +1,492 @@
+// map_kernels.hip -- the read-mapping hot path on gfx950.
+//
+// Upstream per-read path (searcher.hpp:386-539): reverse-complement the read, 12-mer table lookup
+// (init_exact_match :83-96), backward search (exec_exact_match :102-105, two rank queries per base),
+// suppression test (:415), locate (level-0 scan :424-443 + find_possible :460-503), push_position
+// filters (:504-539).  Here:
+//   k_search : two lanes per read.  One 128-byte Block2 access advances BOTH ends of the SA interval by
+//              TWO bases; the pair splits the four bit planes (16 B per lane) and each lane finishes
+//              one end of the interval.  Unique hits are located by one 8-byte gather of sa_full and
+//              filtered in place; multi-hit reads are queued.
+//   k_multi  : the upstream depth-first locate, statement for statement, for the queued reads.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/sbwt_amd.h"
+#include "index_impl.hpp"
+#include "rank_device.h"
+
+namespace sbwt {
+
+struct Counters {
+  unsigned long long hit_count;    // slots handed out in hits[]
+  unsigned long long multi_count;  // reads queued for k_multi
+  unsigned int overflow;           // hits[] too small
+  unsigned int pad;
+};
+
+struct MapArgs {
+  const uint32_t* packed;
+  const uint32_t* lens;
+  uint64_t n_reads;
+  uint32_t wpr;    // 32-bit words per read record (multiple of 4)
+  int strand;
+  uint64_t limit;  // (uint64_t)(int64_t)limitNumber: the upstream comparison is unsigned (searcher.hpp:415)
+  sbwt_read_result* results;
+  sbwt_hit* hits;
+  uint64_t hits_cap;
+  Counters* ctr;
+  uint32_t* multi_queue;
+};
+
+struct Frame {  // one activation of find_possible
+  uint64_t pf, pe;
+  uint32_t next_c, pad;
+};
+
+constexpr uint32_t kFlagInvalid = 0x80000000u;  // read shorter than 12 or longer than its record (never from sbwt_pack_reads)
+
+__device__ __forceinline__ void shift128(uint4& w, const int s) {
+  w.x = __builtin_amdgcn_alignbit(w.y, w.x, s);
+  w.y = __builtin_amdgcn_alignbit(w.z, w.y, s);
+  w.z = __builtin_amdgcn_alignbit(w.w, w.z, s);
+  w.w >>= s;
+}
+
+// rank2 for one end of the interval from one Block2: K2[code] + #{j < i : code(j) == code}
+struct Step2 {
+  uint64_t mask;  // positions of the block whose code matches
+  uint64_t base;  // superblock absolute + block relative count
+};
+__device__ __forceinline__ Step2 load_step2(const DeviceIndex& ix, uint64_t blk, uint32_t code, uint32_t sub) {
+  const Block2* b = ix.blocks2 + blk;
+  // lane 0 of the pair reads planes 0,1 (bits of y), lane 1 planes 2,3 (bits of x): 16 bytes each, one line
+  const uint4 pl = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(b) + 16 * sub);
+  const uint32_t cn = b->cnt[code];
+  const uint64_t sb = ix.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code];
+  const uint64_t pa = ((uint64_t)pl.y << 32) | pl.x, pb = ((uint64_t)pl.w << 32) | pl.z;
+  const uint32_t kb = code >> (2 * sub);
+  const uint64_t part = ((kb & 1) ? pa : ~pa) & ((kb & 2) ? pb : ~pb);
+  Step2 s;
+  s.mask = part & pair_swap64(part);
+  s.base = sb + cn;
+  return s;
+}
+__device__ __forceinline__ uint64_t rank2_correction(const DeviceIndex& ix, uint32_t code, uint64_t i) {
+  return (uint64_t)(ix.special_pos[0] < i && code == ix.special_code[0]) +
+         (uint64_t)(ix.special_pos[1] < i && code == ix.special_code[1]);
+}
+
+// searcher.hpp:504-539 for one lane
+__device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
+                                                   sbwt_hit* out) {
+  bool is_rc = false;
+  if (position >= ix.real_size) {
+    is_rc = true;
+    position = ix.real_size * 2 - position - L;
+  }
+  if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
+  const uint32_t c1 = upper_bound_minus1(ix.chr_start, ix.n_chr, position);
+  const uint32_t c3 = upper_bound_minus1(ix.chr_start, ix.n_chr, position + L - 1);
+  if (c1 != c3) return false;
+  const uint32_t n1 = upper_bound_minus1(ix.npos_key, ix.n_npos, position);
+  const uint32_t n3 = upper_bound_minus1(ix.npos_key, ix.n_npos, position + L - 1);
+  if (n1 != n3) return false;
+  out->pos0 = position - ix.chr_start[c1] + ix.npos_val[n1];
+  out->chr_id = c1;
+  out->is_rc = is_rc ? 1u : 0u;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapArgs a) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r = tid >> 1;
+  const uint32_t sub = (uint32_t)(tid & 1);
+  if (r >= a.n_reads) return;  // both lanes of a pair leave together
+  const uint32_t L = a.lens[r];
+  const uint32_t* rp = a.packed + r * (uint64_t)a.wpr;
+  uint64_t lo = 0, hi = 0;
+  uint32_t flags = 0;
+  if (L < (uint32_t)kKmer || L > a.wpr * 16u) {
+    flags = kFlagInvalid;
+  } else {
+    // bases 0..63; base j sits at bits 2j.  The upstream query is RC(read): walking it from its end is
+    // walking the read from its start with every base complemented (code ^ 3).
+    uint4 w = *reinterpret_cast<const uint4*>(rp);
+    // init_exact_match (searcher.hpp:83-96): sum_k q[L-12+k] * 4^(11-k) with q[L-12+k] = 3 - read[11-k]
+    const uint32_t kmer = (~w.x) & 0xFFFFFFu;
+    const uint64_t mine = ix.c_functions[kmer + sub];
+    const uint64_t theirs = pair_swap64(mine);
+    lo = sub ? theirs : mine;
+    hi = sub ? mine : theirs;
+    shift128(w, 24);
+    uint32_t j = kKmer;
+    while (j + 1 < L && lo < hi) {
+      if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
+      const uint32_t two = (w.x & 15u) ^ 15u;          // complement of read[j], read[j+1]
+      const uint32_t code = ((two & 3u) << 2) | (two >> 2);  // x = first prepended base, y = second
+      const uint64_t b_lo = lo >> 6;
+      const bool same = ((hi - 1) >> 6) == b_lo;
+      const uint64_t my_i = sub ? hi : lo;
+      const Step2 s1 = load_step2(ix, b_lo, code, sub);
+      const uint32_t o1 = sub ? (uint32_t)(hi - (b_lo << 6)) : (uint32_t)(lo & 63);
+      uint64_t val = s1.base + (uint64_t)__popcll(s1.mask & below(o1));
+      if (__ballot(!same)) {  // wave-uniform: only the first steps of a read have ends in different blocks
+        const Step2 s2 = load_step2(ix, hi >> 6, code, sub);
+        const uint64_t v2 = s2.base + (uint64_t)__popcll(s2.mask & below((uint32_t)(hi & 63)));
+        if (sub && !same) val = v2;
+      }
+      val -= rank2_correction(ix, code, my_i);
+      const uint64_t other = pair_swap64(val);
+      const uint64_t nlo = sub ? other : val, nhi = sub ? val : other;
+      if (nlo >= nhi) {
+        // The interval died inside this pair of bases.  Upstream stops after the FIRST base if that one
+        // already emptied it (loop condition lo < hi, searcher.hpp:406), so replay that base alone.
+        const uint64_t v1 = lf1(ix, my_i, code >> 2);
+        const uint64_t w1 = pair_swap64(v1);
+        const uint64_t l1 = sub ? w1 : v1, h1 = sub ? v1 : w1;
+        if (l1 >= h1) { lo = l1; hi = h1; } else { lo = nlo; hi = nhi; }
+        break;
+      }
+      lo = nlo;
+      hi = nhi;
+      j += 2;
+      shift128(w, 4);
+    }
+    if (j + 1 == L && lo < hi) {  // odd number of steps: last base alone
+      if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
+      const uint32_t c = (w.x & 3u) ^ 3u;
+      const uint64_t v1 = lf1(ix, sub ? hi : lo, c);
+      const uint64_t w1 = pair_swap64(v1);
+      lo = sub ? w1 : v1;
+      hi = sub ? v1 : w1;
+    }
+  }
+
+  int32_t nh = 0;
+  uint64_t first_hit = 0;
+  if (hi > lo) {
+    const uint64_t m = hi - lo;
+    if (m > a.limit) {
+      flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
+    } else if (m == 1) {
+      const uint64_t p0 = ix.sa_full[lo];
+      if (p0 != kNoPosition) {
+        // push_position (searcher.hpp:504-539); the pair splits the two ends of the alignment
+        uint64_t position = p0;
+        bool is_rc = false;
+        if (position >= ix.real_size) {
+          is_rc = true;
+          position = ix.real_size * 2 - position - L;
+        }
+        bool ok = !((a.strand == 0 && !is_rc) || (a.strand == 1 && is_rc));
+        if (ok) {
+          const uint64_t q = position + (sub ? (uint64_t)L - 1 : 0);
+          const uint32_t ci = upper_bound_minus1(ix.chr_start, ix.n_chr, q);
+          const uint32_t ni = upper_bound_minus1(ix.npos_key, ix.n_npos, q);
+          ok = (ci == pair_swap(ci)) && (ni == pair_swap(ni));
+          if (ok) {
+            // one slot in hits[], handed out with one atomic per wave
+            const bool writer = sub == 0;
+            const uint64_t wmask = __ballot(writer);
+            const uint32_t lane = threadIdx.x & 63;
+            const int leader = __ffsll((unsigned long long)wmask) - 1;
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(&a.ctr->hit_count, (unsigned long long)__popcll(wmask));
+            base = ((unsigned long long)__shfl((int)(base >> 32), leader) << 32) |
+                   (unsigned int)__shfl((int)(base & 0xffffffffu), leader);
+            if (writer) {
+              const uint64_t slot = base + (uint64_t)__popcll(wmask & ((1ull << lane) - 1));
+              if (slot < a.hits_cap) {
+                sbwt_hit h;
+                h.pos0 = position - ix.chr_start[ci] + ix.npos_val[ni];
+                h.chr_id = ci;
+                h.is_rc = is_rc ? 1u : 0u;
+                a.hits[slot] = h;
+                first_hit = slot;
+                nh = 1;
+              } else {
+                atomicOr(&a.ctr->overflow, 1u);
+              }
+            }
+          }
+        }
+      }
+    } else if (sub == 0) {
+      // multi-hit read: reserve m slots and hand the read to k_multi
+      const uint64_t slot = atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
+      if (slot + m <= a.hits_cap) {
+        first_hit = slot;
+        const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
+        a.multi_queue[q] = (uint32_t)r;
+      } else {
+        atomicOr(&a.ctr->overflow, 1u);
+      }
+    }
+  }
+  if (sub == 0) {
+    sbwt_read_result res;
+    res.sa_lo = lo;
+    res.sa_hi = hi;
+    res.first_hit = first_hit;
+    res.nh = nh;
+    res.flags = flags;
+    a.results[r] = res;
+  }
+}
+
+// ---- multi-hit locate: the upstream DFS, one lane per queued read -----------------------------
+struct MultiState {
+  const DeviceIndex* ix;
+  sbwt_hit* out;
+  uint64_t cap;    // slots reserved = raw interval size
+  uint64_t nres;   // accepted pushes (VARS.result.size())
+  uint32_t L;
+  int strand;
+  uint32_t truncated;
+};
+
+__device__ __forceinline__ void multi_push(MultiState& S, uint64_t position) {
+  sbwt_hit h;
+  if (!push_position_lane(*S.ix, position, S.L, S.strand, &h)) return;
+  if (S.nres < S.cap) S.out[S.nres] = h; else S.truncated = 1;
+  S.nres++;
+}
+
+// for i in [f, e): if fbwt[i] == 0 and i is in location_table -> push(len + SA[i]); returns true when the
+// upstream loop returned early (interval of size 1 whose position was sampled, searcher.hpp:495-496)
+__device__ __forceinline__ bool scan_sampled(MultiState& S, uint64_t f, uint64_t e, uint64_t len, bool single_returns) {
+  const DeviceIndex& ix = *S.ix;
+  const uint64_t bf = f >> 6, be = (e - 1) >> 6;
+  for (uint64_t bb = bf; bb <= be; ++bb) {
+    const Block1* b = ix.blocks1 + bb;
+    const uint64_t sampled = b->sampled, sbase = b->sampled_base;
+    const uint32_t o_lo = bb == bf ? (uint32_t)(f & 63) : 0u;
+    const uint32_t o_hi = bb == be ? (uint32_t)((e - 1) & 63) + 1u : 64u;
+    uint64_t bits = sampled & below(o_hi) & ~below(o_lo);
+    while (bits) {
+      const uint32_t o = (uint32_t)__ffsll((unsigned long long)bits) - 1u;
+      bits &= bits - 1;
+      const uint64_t sa = ix.loc_vals[sbase + (uint64_t)__popcll(sampled & below(o))];
+      multi_push(S, len + sa);
+      if (single_returns && e - f == 1) return true;
+    }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapArgs a, Frame* __restrict__ stacks,
+                                               uint32_t lanes_total) {
+  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t qn = a.ctr->multi_count;
+  Frame* stack = stacks + (uint64_t)lane_global * ix.interval;  // frames 1 .. interval-1
+  for (uint64_t q = lane_global; q < qn; q += lanes_total) {
+    const uint32_t r = a.multi_queue[q];
+    sbwt_read_result res = a.results[r];
+    const uint64_t lo = res.sa_lo, hi = res.sa_hi;
+    MultiState S;
+    S.ix = &ix;
+    S.out = a.hits + res.first_hit;
+    S.cap = hi - lo;
+    S.nres = 0;
+    S.L = a.lens[r];
+    S.strand = a.strand;
+    S.truncated = 0;
+    // VARS.maybe_result_number is an int compared against a size_t (searcher.hpp:412,464)
+    const uint64_t maybe = (uint64_t)(int64_t)(int32_t)(uint32_t)(hi - lo);
+    // level 0 (searcher.hpp:424-443); the break there needs an interval of size 1, never the case here
+    scan_sampled(S, lo, hi, 0, false);
+    // find_possible (searcher.hpp:460-503), recursion unrolled onto an explicit stack
+    uint32_t d = 1;
+    stack[1].pf = lo; stack[1].pe = hi; stack[1].next_c = 0;
+    while (d >= 1) {
+      Frame& f = stack[d];
+      if (f.next_c == 4) { --d; continue; }
+      const uint32_t c = f.next_c++;
+      if ((uint64_t)d >= ix.interval) continue;
+      if (S.nres == maybe) continue;
+      const uint64_t nf = lf1(ix, f.pf, c), ne = lf1(ix, f.pe, c);
+      if (nf >= ne) continue;
+      if (scan_sampled(S, nf, ne, d, true)) continue;
+      if ((uint64_t)d + 1 < ix.interval) {  // a deeper call would return at once (len >= interval)
+        ++d;
+        stack[d].pf = nf; stack[d].pe = ne; stack[d].next_c = 0;
+      }
+    }
+    res.nh = (int32_t)(S.nres < S.cap ? S.nres : S.cap);
+    if (S.truncated) res.flags |= SBWT_RF_TRUNCATED;
+    a.results[r] = res;
+  }
+}
+
+}  // namespace sbwt
+
+// ---------------------------------------------------------------------------------------------------
+using namespace sbwt;
+
+struct sbwt_ctx {
+  const sbwt_index* ix = nullptr;
+  hipStream_t stream = nullptr;
+  uint64_t max_reads = 0;
+  Counters* d_ctr = nullptr;
+  Counters* h_ctr = nullptr;  // pinned
+  uint32_t* d_queue = nullptr;
+  Frame* d_stacks = nullptr;
+  uint32_t multi_lanes = 0;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_ms[3] = {0, 0, 0};
+  // staging for the host-buffer entry point
+  uint32_t *d_packed = nullptr, *d_lens = nullptr;
+  sbwt_read_result* d_results = nullptr;
+  sbwt_hit* d_hits = nullptr;
+  uint64_t staged_words = 0, staged_reads = 0, staged_hits = 0;
+};
+
+extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ctx** out) {
+  if (!ix || !out || max_reads == 0 || max_reads > 0xffffffffull) {
+    set_error("sbwt_ctx_create: bad argument (max_reads must be in 1..2^32-1)");
+    return SBWT_ERR_ARG;
+  }
+  SBWT_HIP(hipSetDevice(ix->device));
+  sbwt_ctx* c = new (std::nothrow) sbwt_ctx;
+  if (!c) return SBWT_ERR_NOMEM;
+  c->ix = ix;
+  c->max_reads = max_reads;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&c->d_ctr, sizeof(Counters));
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, sizeof(Counters));
+  if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
+  // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
+  c->multi_lanes = 256u * 1024u;
+  if (c->multi_lanes > max_reads) c->multi_lanes = (uint32_t)((max_reads + 255) / 256 * 256);
+  if (e == hipSuccess) e = hipMalloc(&c->d_stacks, (uint64_t)c->multi_lanes * ix->d.interval * sizeof(Frame));
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+  if (e != hipSuccess) {
+    sbwt_ctx_free(c);
+    return hip_fail(e, "sbwt_ctx_create", __FILE__, __LINE__);
+  }
+  *out = c;
+  return SBWT_OK;
+}
+
+extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->ix->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  hipFree(c->d_ctr);
+  if (c->h_ctr) hipHostFree(c->h_ctr);
+  hipFree(c->d_queue);
+  hipFree(c->d_stacks);
+  hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits);
+  for (int k = 0; k < 3; ++k)
+    if (c->ev[k]) hipEventDestroy(c->ev[k]);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" void* sbwt_ctx_stream(const sbwt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int sbwt_ctx_last_timing(const sbwt_ctx* c, float ms[3]) {
+  if (!c || !ms) return SBWT_ERR_ARG;
+  for (int k = 0; k < 3; ++k) ms[k] = c->last_ms[k];
+  return SBWT_OK;
+}
+
+extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                                     uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results,
+                                     sbwt_hit* d_hits, uint64_t hits_cap, uint64_t* n_hits_host) {
+  if (!c || (n_reads && (!d_packed || !d_lens || !d_results)) || (hits_cap && !d_hits)) {
+    set_error("sbwt_map_batch_device: null pointer");
+    return SBWT_ERR_ARG;
+  }
+  if (n_reads > c->max_reads || words_per_read == 0 || (words_per_read & 3u)) {
+    set_error("sbwt_map_batch_device: n_reads exceeds the ctx capacity or words_per_read is not a multiple of 4");
+    return SBWT_ERR_ARG;
+  }
+  if (n_hits_host) *n_hits_host = 0;
+  if (n_reads == 0) return SBWT_OK;
+  SBWT_HIP(hipSetDevice(c->ix->device));
+  MapArgs a;
+  a.packed = d_packed;
+  a.lens = d_lens;
+  a.n_reads = n_reads;
+  a.wpr = words_per_read;
+  a.strand = strand;
+  a.limit = (uint64_t)(int64_t)limit;
+  a.results = d_results;
+  a.hits = d_hits;
+  a.hits_cap = hits_cap;
+  a.ctr = c->d_ctr;
+  a.multi_queue = c->d_queue;
+  SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+  SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
+  const uint32_t grid = (uint32_t)((n_reads * 2 + 255) / 256);
+  k_search<<<grid, 256, 0, c->stream>>>(c->ix->d, a);
+  SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
+  k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(c->ix->d, a, c->d_stacks, c->multi_lanes);
+  SBWT_HIP(hipEventRecord(c->ev[2], c->stream));
+  SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+  SBWT_HIP(hipStreamSynchronize(c->stream));
+  SBWT_HIP(hipGetLastError());
+  hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[2]);
+  hipEventElapsedTime(&c->last_ms[1], c->ev[0], c->ev[1]);
+  hipEventElapsedTime(&c->last_ms[2], c->ev[1], c->ev[2]);
+  if (c->h_ctr->overflow) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided",
+             (unsigned long long)c->h_ctr->hit_count, (unsigned long long)hits_cap);
+    set_error(msg);
+    if (n_hits_host) *n_hits_host = c->h_ctr->hit_count;  // what a retry needs
+    return SBWT_ERR_CAPACITY;
+  }
+  if (n_hits_host) *n_hits_host = c->h_ctr->hit_count;
+  return SBWT_OK;
+}
+
+template <typename T>
+static int ensure(T** p, uint64_t* have, uint64_t need) {
+  if (*have >= need) return 0;
+  if (*p) hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  hipError_t e = hipMalloc(p, need * sizeof(T));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(staging)", __FILE__, __LINE__);
+  *have = need;
+  return 0;
+}
+
+extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_t* lens, uint64_t n_reads,
+                              uint32_t words_per_read, int limit, int strand, sbwt_read_result* results,
+                              sbwt_hit* hits, uint64_t hits_cap, uint64_t* n_hits) {
+  if (!c || (n_reads && (!packed || !lens || !results)) || (hits_cap && !hits)) {
+    set_error("sbwt_map_batch: null pointer");
+    return SBWT_ERR_ARG;
+  }
+  if (n_hits) *n_hits = 0;
+  if (n_reads == 0) return SBWT_OK;
+  SBWT_HIP(hipSetDevice(c->ix->device));
+  const uint64_t words = n_reads * words_per_read;
+  uint64_t lens_have = c->staged_reads, res_have = c->staged_reads;
+  if (int rc = ensure(&c->d_packed, &c->staged_words, words)) return rc;
+  if (int rc = ensure(&c->d_lens, &lens_have, n_reads)) return rc;
+  if (int rc = ensure(&c->d_results, &res_have, n_reads)) return rc;
+  c->staged_reads = lens_have < res_have ? lens_have : res_have;
+  if (int rc = ensure(&c->d_hits, &c->staged_hits, hits_cap ? hits_cap : 1)) return rc;
+  SBWT_HIP(hipMemcpyAsync(c->d_packed, packed, words * 4, hipMemcpyHostToDevice, c->stream));
+  SBWT_HIP(hipMemcpyAsync(c->d_lens, lens, n_reads * 4, hipMemcpyHostToDevice, c->stream));
+  uint64_t nh = 0;
+  int rc = sbwt_map_batch_device(c, c->d_packed, c->d_lens, n_reads, words_per_read, limit, strand, c->d_results,
+                                 c->d_hits, hits_cap, &nh);
+  if (rc != SBWT_OK) {
+    if (n_hits) *n_hits = nh;
+    return rc;
+  }
+  SBWT_HIP(hipMemcpyAsync(results, c->d_results, n_reads * sizeof(sbwt_read_result), hipMemcpyDeviceToHost, c->stream));
+  if (nh) SBWT_HIP(hipMemcpyAsync(hits, c->d_hits, nh * sizeof(sbwt_hit), hipMemcpyDeviceToHost, c->stream));
+  SBWT_HIP(hipStreamSynchronize(c->stream));
+  if (n_hits) *n_hits = nh;
+  return SBWT_OK;
+}
