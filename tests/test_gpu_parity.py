@@ -1,0 +1,202 @@
+"""GPU: parity of the HIP path (through the C ABI) with the oracle and with the golden SAM files."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+def fq_reads(path):
+    lines = open(path).read().split("\n")
+    return [lines[i + 1].strip() for i in range(0, len(lines) - 3, 4)]
+
+
+def genome_text(fa):
+    return "".join(l.strip() for l in open(fa) if not l.startswith(">")).upper()
+
+
+def assert_same(sb, ctx, oix, reads, limit=1000, strand=2):
+    packed, lens = sb.pack_reads(reads)
+    res, hits = ctx.map_batch(packed, lens, limit=limit, strand=strand)
+    lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand)
+    np.testing.assert_array_equal(res["sa_lo"], lo)     # identical SA intervals, dead reads included
+    np.testing.assert_array_equal(res["sa_hi"], hi)
+    np.testing.assert_array_equal(res["nh"], nh)
+    assert int(nh.sum()) == len(ohits)
+    for r in np.nonzero(nh)[0]:
+        a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
+        b = ohits[int(first[r]): int(first[r]) + int(nh[r])]
+        assert np.array_equal(a, b), "read %d: hit list differs (order matters)" % r
+    return res, hits
+
+
+@pytest.fixture(scope="module")
+def sb():
+    import sbwt_amd
+    assert os.path.exists(sbwt_amd.lib_path()), "libsbwt_amd.so must be built in-tree before GPU tests"
+    assert sbwt_amd.device_count() >= 1
+    return sbwt_amd
+
+
+@pytest.fixture(scope="module")
+def loaded(sb, oracle, golden_indexes):
+    out = {}
+    for g, prefix in golden_indexes.items():
+        out[g] = (sb.Index.load(prefix), oracle.OracleIndex.load(prefix))
+    yield out
+    for ix, oix in out.values():
+        ix.close()
+        oix.close()
+
+
+@pytest.mark.parametrize("g", ["g1", "g2"])
+@pytest.mark.parametrize("strand", [2, 0, 1])
+def test_golden_reads_match_oracle(sb, loaded, golden_dir, g, strand):
+    ix, oix = loaded[g]
+    reads = [r for r in fq_reads(os.path.join(golden_dir, g + ".fq")) if len(r) >= 12]
+    ctx = sb.Context(ix, len(reads))
+    assert_same(sb, ctx, oix, reads, strand=strand)
+    ctx.close()
+
+
+@pytest.mark.parametrize("limit", [0, 1, 2, 3, 1000, -1])
+def test_suppression_limit(sb, loaded, golden_dir, limit):
+    ix, oix = loaded["g2"]
+    reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
+    ctx = sb.Context(ix, len(reads))
+    res, _ = assert_same(sb, ctx, oix, reads, limit=limit)
+    if limit == 2:
+        assert (res["flags"][:2] & sb.RF_SUPPRESSED).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("g", ["g1", "g2"])
+def test_random_reads_all_lengths(sb, loaded, golden_dir, g):
+    """substrings of both strands, lengths 12..200 (odd and even step counts, 1..4 sixteen-byte chunks),
+    30 % with one substitution so the interval dies at every possible step parity"""
+    ix, oix = loaded[g]
+    seq = genome_text(os.path.join(golden_dir, g + ".fa"))
+    rng = np.random.default_rng(11)
+    reads = []
+    for L in list(range(12, 40)) + [49, 50, 63, 64, 65, 66, 100, 127, 128, 129, 193, 200]:
+        for _ in range(120):
+            p = int(rng.integers(0, len(seq) - L))
+            s = seq[p:p + L]
+            if "N" in s:
+                continue
+            if rng.random() < 0.5:
+                s = s.translate(COMP)[::-1]
+            if rng.random() < 0.3:
+                k = int(rng.integers(0, L))
+                s = s[:k] + "ACGT"[int(rng.integers(0, 4))] + s[k + 1:]
+            reads.append(s)
+    ctx = sb.Context(ix, len(reads))
+    res, _ = assert_same(sb, ctx, oix, reads)
+    assert (res["nh"] > 0).sum() > len(reads) // 2
+    ctx.close()
+
+
+def test_edge_reads(sb, loaded, golden_dir):
+    """poly-A / poly-T (the '$' row and the false candidates at the end of the text), text ends,
+    chromosome-spanning and N-gap-spanning reads, repeats with 3 and 6 hits"""
+    ix, oix = loaded["g2"]
+    fa = os.path.join(golden_dir, "g2.fa")
+    chroms = []
+    for line in open(fa):
+        if line.startswith(">"):
+            chroms.append("")
+        else:
+            chroms[-1] += line.strip().upper()
+    fwd = "".join(c.replace("N", "") for c in chroms)
+    rcs = fwd.translate(COMP)[::-1]
+    reads = ["A" * 12, "T" * 12, "A" * 30, "C" * 13, "G" * 64, "ACGT" * 5,
+             fwd[:12], fwd[:13], fwd[-12:], fwd[-13:], fwd[-40:], rcs[:12], rcs[-12:], rcs[-25:],
+             fwd[3590:3610], fwd[3600 - 12:3600], fwd[3600:3612], fwd[3708:3732], fwd[3715:3727]]
+    rep = chroms[0][1000:1300]
+    for a, b in ((0, 12), (0, 100), (5, 90), (100, 112), (150, 300), (280, 300)):
+        reads += [rep[a:b], rep[a:b].translate(COMP)[::-1]]
+    ctx = sb.Context(ix, len(reads))
+    res, _ = assert_same(sb, ctx, oix, reads)
+    assert res["nh"].max() >= 3
+    ctx.close()
+
+
+def test_empty_batch_and_capacity(sb, loaded, golden_dir):
+    ix, oix = loaded["g2"]
+    ctx = sb.Context(ix, 16)
+    res, hits = ctx.map_batch(np.zeros((0, 4), np.uint32), np.zeros(0, np.uint32))
+    assert len(res) == 0 and len(hits) == 0
+    reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
+    packed, lens = sb.pack_reads(reads)
+    with pytest.raises(sb.SbwtError) as e:       # 9 hit slots needed
+        ctx.map_batch(packed, lens, hits_cap=4)
+    assert e.value.code == -7
+    with pytest.raises(sb.SbwtError) as e:       # more reads than the ctx was sized for
+        ctx.map_batch(np.zeros((17, 4), np.uint32), np.full(17, 12, np.uint32))
+    assert e.value.code == -4
+    ctx.close()
+
+
+@pytest.mark.parametrize("g", ["g1", "g2"])
+def test_map_fastq_sam_is_byte_identical_to_reference(sb, loaded, golden_dir, tmp_path, g):
+    gold = json.load(open(os.path.join(golden_dir, "golden.json")))
+    ix, _ = loaded[g]
+    for nt in (1, 3):
+        sam = str(tmp_path / ("o%d.sam" % nt))
+        stats = ix.map_fastq(os.path.join(golden_dir, g + ".fq"), sam, n_threads=nt)
+        data = open(sam, "rb").read()
+        assert hashlib.md5(data).hexdigest() == gold[g]["ref_sam_md5"]
+        assert stats[0] == (20 if g == "g1" else 8)
+
+
+def test_map_fastq_variants_match_oracle(sb, loaded, golden_dir, tmp_path):
+    ix, oix = loaded["g2"]
+    fq = os.path.join(golden_dir, "g2.fq")
+    for kw in ({"limit": 2}, {"strand": 0}, {"strand": 1}, {"limit": 0}):
+        a, b = str(tmp_path / "a.sam"), str(tmp_path / "b.sam")
+        st = ix.map_fastq(fq, a, **kw)
+        rc, ost = oix.map_fastq(fq, b, **kw)
+        assert rc == 0 and st == ost
+        assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_map_fastq_abort_semantics(sb, loaded, golden_dir, tmp_path):
+    """upstream prints every read before the offending one, then dies: same records, error status"""
+    ix, oix = loaded["g2"]
+    lines = open(os.path.join(golden_dir, "g2.fq")).read().split("\n")
+    fq = tmp_path / "n.fq"
+    fq.write_text("\n".join(lines[:8]) + "\n@bad\nACGTNACGTACGTA\n+\nIIIIIIIIIIIIII\n" + "\n".join(lines[8:]))
+    a, b = str(tmp_path / "a.sam"), str(tmp_path / "b.sam")
+    with pytest.raises(sb.SbwtError) as e:
+        ix.map_fastq(str(fq), a)
+    assert e.value.code == -5 and "read 2" in str(e.value)
+    rc, _ = oix.map_fastq(str(fq), b)
+    assert rc == -1
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # final record without newline is dropped, like upstream's reader
+    fq2 = tmp_path / "nonl.fq"
+    fq2.write_text("\n".join(lines[:-1]))
+    st = ix.map_fastq(str(fq2), a)
+    rc, ost = oix.map_fastq(str(fq2), b)
+    assert st == ost and st[0] == 7
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_corrupt_index_is_rejected(sb, golden_indexes, tmp_path):
+    import shutil
+    src = golden_indexes["g2"]
+    for ext in (".t_table.bwt", ".NposLen.z", ".chrStart", ".chrLen"):
+        shutil.copy(src + ext, str(tmp_path / ("c" + ext)))
+    p = str(tmp_path / "c.t_table.bwt")
+    data = bytearray(open(p, "rb").read())
+    off = 40 + 8 + 8 + 256 * 8 + 8 + (4 ** 12 + 1) * 8 + 5 + 8 + 4 + 65 * 8 + 8 + 8 * 5   # occ_function['A'][5]
+    data[off] ^= 1
+    open(p, "wb").write(bytes(data))
+    with pytest.raises(sb.SbwtError) as e:
+        sb.Index.load(str(tmp_path / "c"))
+    assert e.value.code == -2
