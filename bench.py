@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: mapped reads/s, 50-bp exact reads against a GRCh38-sized index.
+
+Workload (BASELINE.json configs[2]): synthetic genome of 2.94 G non-N bases over 24 contigs with
+GRCh38-like lengths and N runs, 100 M error-free 50-bp reads, both strands, resident in HBM.
+One step = one pass of the hot path (sbwt_map_batch_device) over the whole read batch.
+N > 1: one process per GPU, index replicated, each rank maps its own 100 M reads (weak scaling, no
+data-path collective; torch.distributed/RCCL only for the barrier and the max-over-ranks).
+
+Prints ONE JSON line on rank 0.  torch is plumbing here (device memory for the synthetic inputs,
+barrier); the timed work is the library's HIP kernels behind the C ABI.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# non-N lengths (Mbp) of the 24 GRCh38 primary chromosomes, rounded; sum = 2.94 Gbp
+CHR_MBP = [230.5, 240.5, 198.1, 189.8, 181.3, 170.1, 159.0, 144.8, 121.8, 133.3, 134.5, 133.1,
+           97.98, 88.52, 84.64, 81.81, 82.92, 80.09, 58.44, 63.94, 40.09, 39.16, 154.9, 26.42]
+
+
+def synth_tables(scale):
+    """chromosome starts and the N-offset map (chr_umbiguous_starting_length) of the synthetic genome:
+    every contig starts with a 10 kb N run and has a 50 kb N gap every 40 Mbp."""
+    lens = [max(int(x * 1e6 * scale), 1000) for x in CHR_MBP]
+    chr_start, npos_key, npos_val = [], [], []
+    acc = 0
+    for ln in lens:
+        chr_start.append(acc)
+        off = 10000
+        npos_key.append(acc)
+        npos_val.append(off)
+        p = 40_000_000
+        while p < ln:
+            off += 50000
+            npos_key.append(acc + p)
+            npos_val.append(off)
+            p += 40_000_000
+        acc += ln
+    npos_key.append(acc)
+    npos_val.append(0)
+    return lens, acc, chr_start, npos_key, npos_val
+
+
+def make_genome(torch, dev, g, seed):
+    """g uniform bases -> (uint8 codes [g], packed int32 words [ceil(g/16)+1])"""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    codes = torch.empty(g, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for a in range(0, g, step):
+        b = min(g, a + step)
+        codes[a:b] = torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=gen)
+    words = (g + 15) // 16
+    packed = torch.zeros(words + 1, dtype=torch.int32, device=dev)
+    shifts = (2 * torch.arange(16, device=dev, dtype=torch.int32))
+    wstep = 1 << 24
+    for a in range(0, words, wstep):
+        b = min(words, a + wstep)
+        chunk = torch.zeros((b - a) * 16, dtype=torch.int32, device=dev)
+        hi = min(g, b * 16)
+        chunk[: hi - a * 16] = codes[a * 16: hi].to(torch.int32)
+        packed[a:b] = (chunk.view(-1, 16) << shifts).sum(dim=1, dtype=torch.int32)
+    return codes, packed
+
+
+def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr):
+    """n_reads error-free reads of length L, strand uniform -> packed int32 [n_reads, wpr], lens int32"""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    packed = torch.zeros((n_reads, wpr), dtype=torch.int32, device=dev)
+    shifts = (2 * torch.arange(16, device=dev, dtype=torch.int32))
+    ar = torch.arange(L, device=dev, dtype=torch.int64)
+    step = 1 << 22
+    for a in range(0, n_reads, step):
+        b = min(n_reads, a + step)
+        pos = torch.randint(0, g - L, (b - a,), device=dev, generator=gen, dtype=torch.int64)
+        rev = torch.randint(0, 2, (b - a,), device=dev, generator=gen, dtype=torch.int64).bool()
+        bases = codes[(pos[:, None] + ar[None, :])].to(torch.int32)          # forward strand
+        rc = 3 - bases.flip(1)
+        bases = torch.where(rev[:, None], rc, bases)
+        buf = torch.zeros((b - a, wpr * 16), dtype=torch.int32, device=dev)
+        buf[:, :L] = bases
+        packed[a:b] = (buf.view(b - a, wpr, 16) << shifts).sum(dim=2, dtype=torch.int32)
+    lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
+    return packed, lens
+
+
+def unpack_reads(packed_np, L):
+    """packed uint32 [n, wpr] -> ASCII bytes array [n*L] (numpy, vectorised)"""
+    j = np.arange(L)
+    codes = (packed_np[:, j >> 4] >> (2 * (j & 15)).astype(np.uint32)) & 3
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(-1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=float, default=1.0, help="genome size as a fraction of GRCh38 (debug)")
+    ap.add_argument("--reads", type=int, default=100_000_000)
+    ap.add_argument("--read-len", type=int, default=50)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sbwt_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the library has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    t0 = time.time()
+    L = args.read_len
+    lens_chr, g, chr_start, npos_key, npos_val = synth_tables(args.scale)
+    codes, packed_genome = make_genome(torch, dev, g, seed=38)
+    torch.cuda.synchronize()
+    t_genome = time.time() - t0
+
+    # index: suffix order + tables on the GPU, straight into the HBM layout; rank 0 also exports the
+    # reference-format tables for the CPU baseline leg
+    want_tables = (rank == 0 and not args.no_cpu)
+    t0 = time.time()
+    ix, tables = sbwt_amd.build_index_device(packed_genome.data_ptr(), g, chr_start, npos_key, npos_val, interval=64,
+                                             device=local, want_index=True, want_tables=want_tables)
+    t_index = time.time() - t0
+    del packed_genome
+    info = ix.info()
+
+    wpr = sbwt_amd.words_per_read(L)
+    n_reads = args.reads
+    t0 = time.time()
+    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr)
+    del codes
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    t_reads = time.time() - t0
+
+    res_bytes = n_reads * 32
+    results = torch.empty(res_bytes, dtype=torch.uint8, device=dev)
+    hits_cap = n_reads + (1 << 20)
+    hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
+    ctx = sbwt_amd.Context(ix, n_reads)
+
+    def step():
+        return ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
+                                    hits.data_ptr(), hits_cap, limit=1000, strand=2)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    n_hits = 0
+    for _ in range(args.steps):
+        n_hits = step()                      # synchronises its own stream before returning
+        kernel_ms.append(ctx.last_timing())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = world * n_reads * args.steps / elapsed
+    search_ms = float(np.mean([k[1] for k in kernel_ms]))
+    multi_ms = float(np.mean([k[2] for k in kernel_ms]))
+    res_np = np.frombuffer(results.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
+    mapped = int((res_np["nh"] > 0).sum())
+    multi = int(((res_np["sa_hi"] - res_np["sa_lo"]) > 1).sum())
+    # algorithmic bytes of ONE k_search launch for THIS layout (DESIGN.md "bytes per read"):
+    # 16 B c_functions pair + 128 B per two-base step + 64 B for an odd last base + 8 B sa_full
+    # + 20 B read record/length in + 32 B result + 16 B hit out
+    steps2 = (L - 12) // 2
+    per_read = 16 + 128 * steps2 + 64 * ((L - 12) & 1) + 8 + (wpr * 4 + 4) + 32 + 16
+    algo_bytes = per_read * n_reads
+    achieved = algo_bytes / (search_ms * 1e-3) / 1e9
+    survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
+    roofline = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "launch_ms": round(search_ms, 3), "bytes_per_read": per_read,
+                "accesses_per_s_G": round(n_reads * (steps2 + 2) / (search_ms * 1e-3) / 1e9, 2),
+                "gather_roofline_G_per_s": 48.0,
+                "survey_formula_GBps": round(survey_per_read * n_reads / (search_ms * 1e-3) / 1e9, 1)}
+
+    cpu = None
+    parity = None
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        T = tables.contents
+        L_ = oracle_lib.lib()
+        c4 = (C.c_uint64 * 4)(*T.c_function4)
+        cs = np.asarray(chr_start, dtype=np.uint64)
+        nk = np.asarray(npos_key, dtype=np.uint64)
+        nv = np.asarray(npos_val, dtype=np.uint64)
+        h = L_.sbo_index_wrap(T.interval, T.n, T.first_location, T.real_size, C.addressof(c4), T.c_functions, T.occ[0],
+                              T.occ[1], T.occ[2], T.occ[3], T.occ_len, T.jbwt_seq, T.fbwt, T.location_table, T.n_loc,
+                              cs.size, cs.ctypes.data, nk.size, nk.ctypes.data, nv.ctypes.data)
+        oix = oracle_lib.OracleIndex(h)
+        cores = min(16, os.cpu_count() or 1)
+        probe_n = 20000
+        sample_max = 2_000_000
+        host_packed = packed[:sample_max].cpu().numpy().view(np.uint32)
+        probe = np.concatenate([unpack_reads(host_packed[:probe_n], L), np.zeros(1, np.uint8)])
+        t1 = time.perf_counter()
+        lo, hi, nh, first, ohits = oix.map_batch_raw(probe, np.arange(probe_n + 1, dtype=np.uint64) * L, probe_n,
+                                                     nthreads=1)
+        rate1 = probe_n / (time.perf_counter() - t1)
+        # parity of the same reads through the GPU path
+        gres = res_np[:probe_n]
+        hits_np = np.frombuffer(hits[: int(n_hits) * 16].cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
+        ok = bool(np.array_equal(gres["sa_lo"], lo) and np.array_equal(gres["sa_hi"], hi) and np.array_equal(gres["nh"], nh))
+        for r in np.nonzero(nh)[0][:5000]:
+            a = hits_np[int(gres["first_hit"][r]): int(gres["first_hit"][r]) + int(nh[r])]
+            ok = ok and bool(np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]))
+        parity = {"reads_checked": probe_n, "identical": ok}
+        sample_n = int(min(sample_max, max(probe_n, rate1 * cores * args.cpu_seconds * 0.7)))
+        seqs = unpack_reads(host_packed[:sample_n], L)
+        offsets = (np.arange(sample_n + 1, dtype=np.uint64) * L)
+        t1 = time.perf_counter()
+        oix.map_batch_raw(np.concatenate([seqs, np.zeros(1, np.uint8)]), offsets, sample_n, nthreads=cores)
+        dt = time.perf_counter() - t1
+        cpu = {"value": round(sample_n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": "first %d reads of the same batch, same index (reference-format tables), %d threads; "
+                         "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n)}
+        oix.close()
+        sbwt_amd.host_tables_free(tables)
+
+    line = {
+        "metric": "mapped reads/sec (50bp exact, GRCh38) at 1/8 GPUs; achieved HBM GB/s",
+        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs), %d x %d-bp exact reads per GPU, "
+                               "both strands, -m 1000 -s 2, inputs resident in HBM" % (g / 1e9, n_reads, L),
+                   "index_suffixes": int(info.n), "index_hbm_GB": round(info.device_bytes / 1e9, 2),
+                   "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "hits": int(n_hits),
+                   "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
+                   "setup_s": {"genome": round(t_genome, 1), "index_build": round(t_index, 1), "reads": round(t_reads, 1)},
+                   "parity_vs_oracle": parity},
+    }
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

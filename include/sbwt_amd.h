@@ -94,6 +94,32 @@ const char *sbwt_index_chr_name(const sbwt_index *ix, uint64_t i);
  * full suffix order, which is a valid sort_len-order for every sort_len. */
 int sbwt_build_index(const char *fasta_path, const char *prefix, uint64_t sort_len, uint64_t interval, int device);
 
+/* Reference-format tables in host memory: what Aligner_table::readTable leaves in memory
+ * (aligner_table.hpp:98-161).  Produced by sbwt_index_build_device for callers that want to write the
+ * index files themselves or hand the tables to another consumer.  Free with sbwt_host_tables_free. */
+typedef struct sbwt_host_tables {
+  uint64_t interval, n, first_location, real_size, occ_len, n_loc;
+  uint64_t c_function4[4];   /* c_function['A','C','G','T'] */
+  uint64_t *c_functions;     /* 4^12 + 1 */
+  uint64_t *occ[4];          /* occ_function['A','C','G','T'], occ_len entries each */
+  uint64_t *location_table;  /* n_loc pairs (i, SA[i]) */
+  uint8_t *jbwt_seq;         /* n/4 + 1 bytes */
+  uint8_t *fbwt;             /* n bytes */
+} sbwt_host_tables;
+
+/* Replaces Indexer::build_index (indexer.hpp:165-229: suffix ordering + Aligner_table::createAllTable)
+ * for a genome already on the device: d_fwd_packed is a DEVICE pointer to the concatenated ACGT-only
+ * forward text, 2-bit codes in the read encoding below (16 bases per 32-bit word).  chr_* / npos_* are
+ * the host tables Genome_pre_handler::run_handler would have written (genome_pre_handler.hpp:183-236).
+ * Either output may be NULL. */
+int sbwt_index_build_device(int device, const uint32_t *d_fwd_packed, uint64_t g, uint64_t interval,
+                            uint64_t n_chr, const uint64_t *chr_start, const char *const *chr_names,
+                            uint64_t n_npos, const uint64_t *npos_key, const uint64_t *npos_val,
+                            sbwt_index **out_index, sbwt_host_tables **out_tables);
+void sbwt_host_tables_free(sbwt_host_tables *t);
+/* Aligner_table::saveTable (aligner_table.hpp:213): writes prefix.t_table.bwt byte-compatible with upstream */
+int sbwt_host_tables_save(const sbwt_host_tables *t, const char *table_path);
+
 /* ---- mapping ----------------------------------------------------------------------------- */
 
 /* One worker: a HIP stream plus scratch sized for batches of up to max_reads reads. */

@@ -6,5 +6,5 @@ is missing.
 """
 from .api import (  # noqa: F401
     SbwtError, Index, Context, Hit, ReadResult, lib, lib_path, pack_reads, words_per_read,
-    device_count, build_index, RF_SUPPRESSED, RF_TRUNCATED,
+    device_count, build_index, build_index_device, host_tables_free, host_tables_save, HostTables, RF_SUPPRESSED, RF_TRUNCATED,
 )

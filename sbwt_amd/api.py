@@ -30,6 +30,14 @@ class IndexInfo(C.Structure):
                 ("n_loc", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int)]
 
 
+class HostTables(C.Structure):
+    """sbwt_host_tables: reference-format tables in host memory (owned by the library)."""
+    _fields_ = [("interval", C.c_uint64), ("n", C.c_uint64), ("first_location", C.c_uint64),
+                ("real_size", C.c_uint64), ("occ_len", C.c_uint64), ("n_loc", C.c_uint64),
+                ("c_function4", C.c_uint64 * 4), ("c_functions", C.c_void_p), ("occ", C.c_void_p * 4),
+                ("location_table", C.c_void_p), ("jbwt_seq", C.c_void_p), ("fbwt", C.c_void_p)]
+
+
 HIT_DTYPE = np.dtype([("pos0", "<u8"), ("chr_id", "<u4"), ("is_rc", "<u4")])
 RESULT_DTYPE = np.dtype([("sa_lo", "<u8"), ("sa_hi", "<u8"), ("first_hit", "<u8"), ("nh", "<i4"), ("flags", "<u4")])
 
@@ -62,6 +70,10 @@ def lib():
     L.sbwt_index_chr_name.argtypes = [vp, u64]
     L.sbwt_index_chr_name.restype = C.c_char_p
     L.sbwt_build_index.argtypes = [C.c_char_p, C.c_char_p, u64, u64, i32]
+    L.sbwt_index_build_device.argtypes = [i32, vp, u64, u64, u64, vp, vp, u64, vp, vp, p(vp), p(p(HostTables))]
+    L.sbwt_host_tables_free.argtypes = [p(HostTables)]
+    L.sbwt_host_tables_free.restype = None
+    L.sbwt_host_tables_save.argtypes = [p(HostTables), C.c_char_p]
     L.sbwt_ctx_create.argtypes = [vp, u64, p(vp)]
     L.sbwt_ctx_free.argtypes = [vp]
     L.sbwt_ctx_free.restype = None
@@ -112,6 +124,32 @@ def pack_reads(reads, wpr=None):
 
 def build_index(fasta, prefix, sort_len=256, interval=64, device=0):
     _check(lib().sbwt_build_index(os.fsencode(fasta), os.fsencode(prefix), sort_len, interval, device))
+
+
+def build_index_device(d_fwd_packed, g, chr_start, npos_key, npos_val, interval=64, device=0, chr_names=None,
+                       want_index=True, want_tables=False):
+    """sbwt_index_build_device: d_fwd_packed is a raw device address. Returns (Index|None, HostTables ptr|None)."""
+    cs = np.ascontiguousarray(chr_start, dtype=np.uint64)
+    nk = np.ascontiguousarray(npos_key, dtype=np.uint64)
+    nv = np.ascontiguousarray(npos_val, dtype=np.uint64)
+    names = None
+    if chr_names is not None:
+        arr = (C.c_char_p * len(chr_names))(*[s.encode() for s in chr_names])
+        names = C.cast(arr, C.c_void_p)
+    h = C.c_void_p()
+    t = C.POINTER(HostTables)()
+    _check(lib().sbwt_index_build_device(device, d_fwd_packed, g, interval, cs.size, cs.ctypes.data, names, nk.size,
+                                         nk.ctypes.data, nv.ctypes.data, C.byref(h) if want_index else None,
+                                         C.byref(t) if want_tables else None))
+    return (Index(h) if want_index else None), (t if want_tables else None)
+
+
+def host_tables_free(t):
+    lib().sbwt_host_tables_free(t)
+
+
+def host_tables_save(t, path):
+    _check(lib().sbwt_host_tables_save(t, os.fsencode(path)))
 
 
 class Index:
