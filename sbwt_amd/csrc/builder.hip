@@ -13,6 +13,7 @@
 // wherever the text allows one, which is a valid sort_len-order for every sort_len <= 270.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <cstring>
 using std::memset;
@@ -71,7 +72,7 @@ __device__ __forceinline__ uint32_t prefix_digits(const Text& T, uint64_t p, int
 
 __global__ __launch_bounds__(256) void k_make_text(const uint32_t* __restrict__ fwd, uint64_t g, uint32_t* __restrict__ text,
                                                    uint64_t n_words) {
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = global_thread();
   if (w >= n_words) return;
   const uint64_t m = 2 * g;
   uint32_t out = 0;
@@ -111,19 +112,19 @@ struct PrefixIs {
 
 __global__ __launch_bounds__(256) void k_keys(Text T, const uint64_t* __restrict__ pos, uint64_t cnt, uint64_t off,
                                               uint64_t* __restrict__ keys) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = global_thread();
   if (t < cnt) keys[t] = key5(T, pos[t] + off);
 }
 
 __global__ __launch_bounds__(256) void k_iota(uint32_t* a, uint64_t cnt) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = global_thread();
   if (t < cnt) a[t] = (uint32_t)t;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gather(const T* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t cnt,
                                                 T* __restrict__ dst) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = global_thread();
   if (t < cnt) dst[t] = src[idx[t]];
 }
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_gather(const T* __restrict__ src, const
 __global__ __launch_bounds__(256) void k_mark_heads(const uint32_t* __restrict__ gid, const uint64_t* __restrict__ key,
                                                     uint64_t cnt, uint32_t* __restrict__ gid_head_idx,
                                                     uint32_t* __restrict__ key_head_flag) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = global_thread();
   if (t >= cnt) return;
   const bool gh = t == 0 || (gid && gid[t] != gid[t - 1]);
   const bool kh = gh || key[t] != key[t - 1];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_slots(const uint32_t* __restrict__ gid,
                                                const uint32_t* __restrict__ key_head_flag, const uint64_t* __restrict__ pos,
                                                uint64_t cnt, uint64_t* __restrict__ sa_part,
                                                uint32_t* __restrict__ head_slot) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = global_thread();
   if (t >= cnt) return;
   const uint32_t slot = (gid ? gid[t] : 0u) + ((uint32_t)t - gid_start[t]);
   if (sa_part) sa_part[slot] = pos[t];
@@ -154,17 +155,32 @@ __global__ __launch_bounds__(256) void k_slots(const uint32_t* __restrict__ gid,
 // tie[t] = element belongs to a (gid,key) run of length >= 2
 __global__ __launch_bounds__(256) void k_tie_flags(const uint32_t* __restrict__ key_head_flag, uint64_t cnt,
                                                    uint8_t* __restrict__ tie) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = global_thread();
   if (t >= cnt) return;
   const bool single = key_head_flag[t] && (t + 1 == cnt || key_head_flag[t + 1]);
   tie[t] = single ? 0 : 1;
+}
+
+// debug: order violations on the first 27 digits and the position checksum
+__global__ __launch_bounds__(256) void k_check_sa(Text T, const uint64_t* __restrict__ sa, uint64_t n,
+                                                  unsigned long long* out) {
+  const uint64_t i = global_thread();
+  unsigned long long v = 0;  // lanes past the end stay in the wave reduction with 0
+  if (i < n) {
+    const uint64_t s = sa[i];
+    if (s > T.m) atomicAdd(&out[1], 1ull);
+    if (i > 0 && key5(T, sa[i - 1]) > key5(T, s)) atomicAdd(&out[0], 1ull);
+    v = s;
+  }
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&out[2], v);
 }
 
 // ---- table emission ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit_bwt(Text T, const uint64_t* __restrict__ sa, uint64_t n, uint64_t interval,
                                                   uint8_t* __restrict__ jbwt, uint8_t* __restrict__ fbwt,
                                                   uint64_t* first_location) {
-  const uint64_t byte = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t byte = global_thread();
   if (byte >= n / 4 + 1) return;
   uint32_t out = 0;
   for (int q = 0; q < 4; ++q) {
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(256) void k_block_counts(const uint8_t* __restrict_
                                                       uint64_t* __restrict__ cA, uint64_t* __restrict__ cC,
                                                       uint64_t* __restrict__ cG, uint64_t* __restrict__ cT,
                                                       uint64_t* __restrict__ cS) {
-  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t k = global_thread();
   if (k >= n_ckpt) return;
   uint64_t c[4] = {0, 0, 0, 0}, s = 0;
   const uint64_t a = k * interval, b = a + interval < n ? a + interval : n;
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void k_block_counts(const uint8_t* __restrict_
 __global__ __launch_bounds__(256) void k_emit_loc(const uint64_t* __restrict__ sa, const uint8_t* __restrict__ fbwt,
                                                   uint64_t n, uint64_t interval, uint64_t n_ckpt,
                                                   const uint64_t* __restrict__ base, uint64_t* __restrict__ loc) {
-  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t k = global_thread();
   if (k >= n_ckpt) return;
   uint64_t o = base[k];
   const uint64_t a = k * interval, b = a + interval < n ? a + interval : n;
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256) void k_emit_loc(const uint64_t* __restrict__ s
 // c_functions, step 1: first SA index of every 12-mer that occurs with 12 real bases (SURVEY.md 8b rule)
 __global__ __launch_bounds__(256) void k_kmer_starts(Text T, const uint64_t* __restrict__ sa, uint64_t n,
                                                      unsigned long long* __restrict__ starts) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = global_thread();
   if (i >= n) return;
   const uint64_t s = sa[i];
   if (s + kKmer > T.m) return;
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(256) void k_base_hist(Text T, unsigned long long* h
   __shared__ unsigned int h[4];
   if (threadIdx.x < 4) h[threadIdx.x] = 0;
   __syncthreads();
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = global_thread();
   const uint64_t n_words = (T.m + 15) / 16;
   if (w < n_words) {
     uint32_t c[4] = {0, 0, 0, 0};
@@ -276,7 +292,7 @@ __global__ __launch_bounds__(256) void k_base_hist(Text T, unsigned long long* h
 }
 
 // ---- host side of the sorter ------------------------------------------------------------------------
-static inline uint32_t blocks_for(uint64_t items) { return (uint32_t)((items + 255) / 256); }
+static inline dim3 blocks_for(uint64_t items) { return grid_items(items, 256); }
 
 struct Scratch {  // growing rocPRIM temporary storage
   void* p = nullptr;
@@ -366,7 +382,7 @@ struct PartitionSorter {
   // pos_a holds the partition's positions on entry
   int run(const Text& T, uint64_t cnt, uint64_t* sa_part) {
     if (cnt == 0) return 0;
-    const uint32_t g = blocks_for(cnt);
+    const dim3 g = blocks_for(cnt);
     k_keys<<<g, 256>>>(T, pos_a.p, cnt, 0, key_a.p);
     if (int rc = sort_pairs(tmp, key_a.p, key_b.p, pos_a.p, pos_b.p, cnt, 63)) return rc;
     // sorted: key_b / pos_b.  Everything is one group (gid = null); find runs of equal keys.
@@ -382,7 +398,7 @@ struct PartitionSorter {
     SBWT_HIP(hipMemcpy(&ns, d_count.p, 8, hipMemcpyDeviceToHost));
     // subset: pos_a (positions), u0 (gid)
     for (uint64_t off = kDigits; ns > 0 && off < (uint64_t)kMaxDepth; off += kDigits) {
-      const uint32_t gs = blocks_for(ns);
+      const dim3 gs = blocks_for(ns);
       k_keys<<<gs, 256>>>(T, pos_a.p, ns, off, key_a.p);            // key_a = next 27 digits (subset order)
       k_iota<<<gs, 256>>>(u1.p, ns);
       if (int rc = sort_pairs(tmp, key_a.p, key_b.p, u1.p, u2.p, ns, 63)) return rc;   // u2 = order by key
@@ -430,6 +446,7 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
   if (int rc = text.alloc(n_words + 8)) return rc;
   SBWT_HIP(hipMemset(text.p, 0, (n_words + 8) * 4));
   k_make_text<<<blocks_for(n_words), 256>>>(d_fwd, g, text.p, n_words);
+  SBWT_LAUNCHED();
   Text T{text.p, m};
 
   // partition depth: smallest D with every partition <= kMaxPartition (expected n / 4^D)
@@ -451,31 +468,50 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
 
   DevBuf<uint64_t> sa;
   if (int rc = sa.alloc(n)) return rc;
+  uint64_t base = 0;
   {
     PartitionSorter S;
     if (int rc = S.reserve(max_part)) return rc;
-    uint64_t base = 0;
     for (uint32_t v = 0; v < n_part; ++v) {
       const uint64_t cnt = hist[v];
       if (cnt == 0) continue;
-      if (D == 0) {
-        // iota of all positions
-        size_t bytes = 0;
-        PrefixIs all{T, 0, 0};
-        SBWT_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint64_t>(0), S.pos_a.p, S.d_count.p, (size_t)n, all));
-        if (int rc = S.tmp.need(bytes)) return rc;
-        SBWT_HIP(rocprim::select(S.tmp.p, bytes, rocprim::counting_iterator<uint64_t>(0), S.pos_a.p, S.d_count.p, (size_t)n, all));
-      } else {
-        size_t bytes = 0;
+      {
+        // positions of this partition, gathered in input slabs of 2^30 (rocPRIM's select indexes its input
+        // with 32 bits; a single call over > 2^32 suffixes silently returns wrong positions)
         PrefixIs pred{T, D, v};
-        SBWT_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint64_t>(0), S.pos_a.p, S.d_count.p, (size_t)n, pred));
-        if (int rc = S.tmp.need(bytes)) return rc;
-        SBWT_HIP(rocprim::select(S.tmp.p, bytes, rocprim::counting_iterator<uint64_t>(0), S.pos_a.p, S.d_count.p, (size_t)n, pred));
+        uint64_t got = 0;
+        for (uint64_t c0 = 0; c0 < n; c0 += (1ull << 30)) {
+          const uint64_t len = std::min<uint64_t>(1ull << 30, n - c0);
+          size_t bytes = 0;
+          SBWT_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint64_t>(c0), S.pos_a.p + got, S.d_count.p, (size_t)len, pred));
+          if (int rc = S.tmp.need(bytes)) return rc;
+          SBWT_HIP(rocprim::select(S.tmp.p, bytes, rocprim::counting_iterator<uint64_t>(c0), S.pos_a.p + got, S.d_count.p, (size_t)len, pred));
+          uint64_t c = 0;
+          SBWT_HIP(hipMemcpy(&c, S.d_count.p, 8, hipMemcpyDeviceToHost));
+          got += c;
+        }
+        if (got != cnt) {
+          set_error("index builder: partition size mismatch");
+          return SBWT_ERR_HIP;
+        }
       }
       if (int rc = S.run(T, cnt, sa.p + base)) return rc;
       base += cnt;
     }
     SBWT_HIP(hipDeviceSynchronize());
+    if (getenv("SBWT_DEBUG")) {
+      DevBuf<unsigned long long> chk;
+      if (int rc = chk.alloc(3)) return rc;
+      SBWT_HIP(hipMemset(chk.p, 0, 24));
+      k_check_sa<<<blocks_for(n), 256>>>(T, sa.p, n, chk.p);
+      SBWT_LAUNCHED();
+      unsigned long long h[3];
+      SBWT_HIP(hipMemcpy(h, chk.p, 24, hipMemcpyDeviceToHost));
+      unsigned long long want = (unsigned long long)((n & 1) ? ((n - 1) / 2) * n : (n / 2) * (n - 1));
+      fprintf(stderr, "[sbwt debug] n=%llu D=%d parts=%u max_part=%llu placed=%llu order_violations=%llu out_of_range=%llu checksum %s\n",
+              (unsigned long long)n, D, n_part, (unsigned long long)max_part, (unsigned long long)base, h[0], h[1],
+              h[2] == want ? "ok" : "BAD");
+    }
   }
 
   // ---- tables ----
@@ -489,6 +525,7 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
   DevBuf<uint64_t> d_first;
   if (int rc = d_first.alloc(1)) return rc;
   k_emit_bwt<<<blocks_for(n / 4 + 1), 256>>>(T, sa.p, n, interval, jbwt, fbwt, d_first.p);
+  SBWT_LAUNCHED();
   SBWT_HIP(hipMemcpy(&raw.first_location, d_first.p, 8, hipMemcpyDeviceToHost));
   raw.jbwt = jbwt;
   raw.fbwt = fbwt;
@@ -518,6 +555,7 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
   if (int rc = R.alloc(&starts, kNumKmer + 1)) return rc;
   SBWT_HIP(hipMemset(starts, 0xff, (kNumKmer + 1) * 8));
   k_kmer_starts<<<blocks_for(n), 256>>>(T, sa.p, n, starts);
+  SBWT_LAUNCHED();
   k_kmer_fill<<<1, 1024>>>(starts, n);
   raw.c_functions = reinterpret_cast<const uint64_t*>(starts);
 

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_planes1(Block1* __restrict__ blocks, ui
                                                  const uint8_t* __restrict__ jbwt, uint64_t jbwt_len,
                                                  const uint8_t* __restrict__ fbwt, const uint64_t* __restrict__ loc,
                                                  uint64_t n_loc, LayoutErrors* err) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t b = global_thread();
   if (b >= n_blocks) return;
   uint64_t plo = 0, phi = 0;
   for (int k = 0; k < 16; ++k) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_planes1(Block1* __restrict__ blocks, ui
 
 __global__ __launch_bounds__(256) void k_loc_vals(const uint64_t* __restrict__ loc, uint64_t n_loc, uint64_t n,
                                                   uint64_t* __restrict__ loc_vals, LayoutErrors* err) {
-  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t k = global_thread();
   if (k >= n_loc) return;
   loc_vals[k] = loc[2 * k + 1];
   if (loc[2 * k] >= n || (k + 1 < n_loc && loc[2 * k] >= loc[2 * k + 2])) atomicAdd(&err->loc_not_sorted, 1ull);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_apply1(Block1* __restrict__ blocks, uin
 // (searcher.hpp:424-443) then find_possible (searcher.hpp:460-503) on a size-1 interval, i.e. follow LF
 // until a sampled position; kNoPosition if depth `interval` or the '$' row is reached first.
 __global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __restrict__ sa_full) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = global_thread();
   if (i >= ix.n) return;
   uint64_t cur = i, t = 0, res = kNoPosition;
   for (;;) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __res
 // ---- blocks2: two-step planes ----------------------------------------------------------------------
 // one wave per index block; lane j owns position 64b + j
 __global__ __launch_bounds__(256) void k_planes2(DeviceIndex ix, Block2* __restrict__ blocks2, uint64_t* special) {
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t gid = global_thread();
   const uint64_t b = gid >> 6;
   if (b >= ix.n_blocks) return;  // wave-uniform
   const uint32_t lane = threadIdx.x & 63;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_apply2(Block2* __restrict__ blocks, uin
 }
 
 // ---------------------------------------------------------------------------------------------------
-static inline uint32_t grid_for(uint64_t items, uint32_t per_block) { return (uint32_t)((items + per_block - 1) / per_block); }
+static inline dim3 grid_for(uint64_t items, uint32_t per_block) { return grid_items(items, per_block); }
 
 int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   DeviceIndex& d = ix->d;
@@ -315,6 +315,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   SBWT_HIP(hipMemset(d_small, 0xff, 2 * sizeof(uint64_t)));
 
   k_planes1<<<grid_for(nb, 256), 256>>>(blocks1, nb, raw.n, raw.jbwt, raw.n / 4 + 1, raw.fbwt, raw.loc, raw.n_loc, d_err);
+  SBWT_LAUNCHED();
   if (raw.n_loc) k_loc_vals<<<grid_for(raw.n_loc, 256), 256>>>(raw.loc, raw.n_loc, raw.n, loc_vals, d_err);
   k_chunk_totals<4, Block1><<<(uint32_t)n_chunks, kChunk>>>(blocks1, nb, chunk_base);
   k_scan_chunks<<<1, 64>>>(chunk_base, n_chunks, 4);
@@ -339,9 +340,11 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   }
 
   k_sa_full<<<grid_for(raw.n, 256), 256>>>(d, sa_full);
+  SBWT_LAUNCHED();
   d.sa_full = sa_full;
 
   k_planes2<<<grid_for(nb * 64, 256), 256>>>(d, blocks2, d_small);
+  SBWT_LAUNCHED();
   k_k2<<<1, 64>>>(d, d_small + 2);
   k_chunk_totals<16, Block2><<<(uint32_t)n_chunks, kChunk>>>(blocks2, nb, chunk_base);
   k_scan_chunks<<<1, 64>>>(chunk_base, n_chunks, 16);

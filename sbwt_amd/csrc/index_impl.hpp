@@ -18,6 +18,22 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     if (e__ != hipSuccess) return ::sbwt::hip_fail(e__, #x, __FILE__, __LINE__); \
   } while (0)
 
+// HIP refuses a launch whose gridDim.x * blockDim.x does not fit 32 bits (hipErrorInvalidConfiguration), and
+// GRCh38 has more than 2^32 suffixes: every per-item kernel is launched on a 2-D grid and linearises it.
+inline dim3 grid2d(uint64_t blocks) {
+  const uint64_t kMaxX = 1ull << 20;
+  if (blocks == 0) blocks = 1;
+  if (blocks <= kMaxX) return dim3((uint32_t)blocks, 1, 1);
+  return dim3((uint32_t)kMaxX, (uint32_t)((blocks + kMaxX - 1) / kMaxX), 1);
+}
+inline dim3 grid_items(uint64_t items, uint32_t per_block = 256) { return grid2d((items + per_block - 1) / per_block); }
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t global_block() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
+__device__ __forceinline__ uint64_t global_thread() { return global_block() * blockDim.x + threadIdx.x; }
+#endif
+// a failed launch must not go unnoticed until some later call happens to report it
+#define SBWT_LAUNCHED() SBWT_HIP(hipGetLastError())
+
 // Reference-format tables resident on the device (temporary inputs of the re-layout).
 struct RawDeviceTables {
   uint64_t interval = 0, n = 0, first_location = 0, real_size = 0;

@@ -102,7 +102,7 @@ __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64
 }
 
 __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapArgs a) {
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t tid = global_thread();
   const uint64_t r = tid >> 1;
   const uint32_t sub = (uint32_t)(tid & 1);
   if (r >= a.n_reads) return;  // both lanes of a pair leave together
@@ -423,8 +423,8 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   a.multi_queue = c->d_queue;
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
-  const uint32_t grid = (uint32_t)((n_reads * 2 + 255) / 256);
-  k_search<<<grid, 256, 0, c->stream>>>(c->ix->d, a);
+  k_search<<<grid_items(n_reads * 2, 256), 256, 0, c->stream>>>(c->ix->d, a);
+  SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
   k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(c->ix->d, a, c->d_stacks, c->multi_lanes);
   SBWT_HIP(hipEventRecord(c->ev[2], c->stream));
