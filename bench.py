@@ -164,26 +164,18 @@ def main():
         return ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
                                     hits.data_ptr(), hits_cap, limit=1000, strand=2)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from sbwt_amd import shard
+    kernel_ms = []
+    last = {"hits": 0}
+
+    def timed_step():
+        last["hits"] = step()                # synchronises its own stream before returning
+        kernel_ms.append(ctx.last_timing())
 
     for _ in range(args.warmup):
         step()
-    kernel_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    n_hits = 0
-    for _ in range(args.steps):
-        n_hits = step()                      # synchronises its own stream before returning
-        kernel_ms.append(ctx.last_timing())
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.timed_steps(timed_step, args.steps, 0, dist=dist, sync=torch.cuda.synchronize, device=dev)
+    n_hits = last["hits"]
 
     if rank != 0:
         if dist is not None:

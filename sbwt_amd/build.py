@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsbwt_amd.so")
 BIN = os.path.join(HERE, "bin", "sbwt")
 SOURCES = ["capi.cpp", "index_file.cpp", "host_pipeline.cpp", "device_index.hip", "map_kernels.hip", "builder.hip"]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-pthread"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]
 
 
 def _stale(target, deps):

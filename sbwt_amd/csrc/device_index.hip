@@ -207,6 +207,119 @@ __global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __res
   sa_full[i] = res;
 }
 
+// ---- text-jump tables ---------------------------------------------------------------------------------
+// A size-1 interval [i, i+1) evolves under exec_exact_match (searcher.hpp:102-105) as the LF chain of row i: base
+// c keeps it alive iff bwt[i] == c (and i is not the '$' row), and the next row is LF(i).  Wherever the tables are
+// LF-consistent -- the row LF(j) reports the text position of row j minus one, and positions map back to their
+// rows one to one -- r such steps are: compare the next r bases with the text implied by the tables, and land on
+// row_tab[p - r].  k_verify_rows finds the rows where that holds; `run` (packed into sa_full) says how far it
+// holds going down from each position, so that an index with unordered ties (the upstream k-ordered sort leaves
+// suffixes equal over sort_len bases in any order) or a damaged one falls back to rank queries exactly there.
+__global__ __launch_bounds__(256) void k_row_scatter(uint64_t n, const uint64_t* __restrict__ sa_full,
+                                                     unsigned long long* __restrict__ row_tab,
+                                                     uint8_t* __restrict__ badpos) {
+  const uint64_t i = global_thread();
+  if (i >= n) return;
+  const uint64_t p = sa_full[i];
+  if (p >= n) return;  // kNoPosition or nonsense: the row claims no position
+  const unsigned long long old = atomicCAS(&row_tab[p], ~0ull, (unsigned long long)i);
+  if (old != ~0ull) badpos[p] = 1;  // two rows report the same position
+}
+
+__global__ __launch_bounds__(256) void k_verify_rows(DeviceIndex ix, const uint64_t* __restrict__ sa_full,
+                                                     const unsigned long long* __restrict__ row_tab,
+                                                     uint8_t* __restrict__ badpos) {
+  const uint64_t j = global_thread();
+  if (j >= ix.n) return;
+  const uint64_t p = sa_full[j];
+  if (p >= ix.n) return;
+  bool bad = row_tab[p] != j;
+  if (!bad && j == ix.first_location) bad = p != 0;  // the '$' row ends every chain: text position 0
+  if (!bad && j != ix.first_location) {
+    if (p == 0) bad = true;
+    else {
+      const Block1* b = ix.blocks1 + (j >> 6);
+      const uint32_t o = (uint32_t)(j & 63);
+      const uint32_t c = (uint32_t)((b->plane_lo >> o) & 1ull) | ((uint32_t)((b->plane_hi >> o) & 1ull) << 1);
+      bad = sa_full[lf1(ix, j, c)] != p - 1;
+    }
+  }
+  if (bad) badpos[p] = 1;
+}
+
+// one thread per 16-base word of textrc
+__global__ __launch_bounds__(256) void k_textrc(DeviceIndex ix, const unsigned long long* __restrict__ row_tab,
+                                                uint32_t* __restrict__ textrc, uint64_t n_words) {
+  const uint64_t w = global_thread();
+  if (w >= n_words) return;
+  const uint64_t m = ix.n - 1;
+  uint32_t out = 0;
+  for (int t = 0; t < 16; ++t) {
+    const uint64_t x = w * 16 + t;
+    uint32_t c = 0;
+    if (x < m) {
+      const uint64_t r = row_tab[m - x];  // text[q] = bwt[row of position q + 1], q = m - 1 - x
+      if (r != ~0ull) {
+        const Block1* b = ix.blocks1 + (r >> 6);
+        const uint32_t o = (uint32_t)(r & 63);
+        c = 3u - ((uint32_t)((b->plane_lo >> o) & 1ull) | ((uint32_t)((b->plane_hi >> o) & 1ull) << 1));
+      }
+    }
+    out |= c << (2 * t);
+  }
+  textrc[w] = out;
+}
+
+constexpr uint64_t kRunChunk = 1024;  // text positions per thread in the run computation
+
+// chunk_last[c] = 1 + the largest bad position of chunk c, or 0
+__global__ __launch_bounds__(256) void k_run_chunks(uint64_t n, const uint8_t* __restrict__ badpos,
+                                                    const unsigned long long* __restrict__ row_tab,
+                                                    uint64_t* __restrict__ chunk_last) {
+  const uint64_t c = global_thread();
+  const uint64_t a = c * kRunChunk;
+  if (a >= n) return;
+  const uint64_t b = a + kRunChunk < n ? a + kRunChunk : n;
+  uint64_t last = 0;
+  for (uint64_t q = a; q < b; ++q)
+    if (badpos[q] || row_tab[q] == ~0ull) last = q + 1;
+  chunk_last[c] = last;
+}
+// in place, one workgroup: running maximum over chunks (n / 1024 entries); each thread owns a contiguous slice
+__global__ __launch_bounds__(1024) void k_run_scan(uint64_t* chunk_last, uint64_t n_chunks) {
+  __shared__ uint64_t slice_max[1024];
+  const uint64_t per = (n_chunks + 1023) / 1024;
+  const uint64_t a = threadIdx.x * per < n_chunks ? threadIdx.x * per : n_chunks;
+  const uint64_t b = a + per < n_chunks ? a + per : n_chunks;
+  uint64_t mx = 0;
+  for (uint64_t c = a; c < b; ++c) mx = chunk_last[c] > mx ? chunk_last[c] : mx;
+  slice_max[threadIdx.x] = mx;
+  __syncthreads();
+  uint64_t acc = 0;
+  for (uint32_t t = 0; t < threadIdx.x; ++t) acc = slice_max[t] > acc ? slice_max[t] : acc;
+  for (uint64_t c = a; c < b; ++c) {
+    const uint64_t v = chunk_last[c];
+    acc = v > acc ? v : acc;
+    chunk_last[c] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_run_apply(uint64_t n, const uint8_t* __restrict__ badpos,
+                                                   const unsigned long long* __restrict__ row_tab,
+                                                   const uint64_t* __restrict__ chunk_last, uint64_t* __restrict__ sa_full) {
+  const uint64_t c = global_thread();
+  const uint64_t a = c * kRunChunk;
+  if (a >= n) return;
+  const uint64_t b = a + kRunChunk < n ? a + kRunChunk : n;
+  uint64_t last = c ? chunk_last[c - 1] : 0;
+  for (uint64_t q = a; q < b; ++q) {
+    const uint64_t r = row_tab[q];
+    if (badpos[q] || r == ~0ull) { last = q + 1; continue; }
+    uint64_t run = q + 1 - last;  // positions q, q-1, ..., q-run+1 are good
+    if (run > kRunMax) run = kRunMax;
+    sa_full[r] = q | (run << kPosBits);  // sa_full[r] == q was verified
+  }
+}
+
 // ---- blocks2: two-step planes ----------------------------------------------------------------------
 // one wave per index block; lane j owns position 64b + j
 __global__ __launch_bounds__(256) void k_planes2(DeviceIndex ix, Block2* __restrict__ blocks2, uint64_t* special) {
@@ -342,6 +455,41 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   k_sa_full<<<grid_for(raw.n, 256), 256>>>(d, sa_full);
   SBWT_LAUNCHED();
   d.sa_full = sa_full;
+  if (raw.n >= (1ull << kPosBits)) {
+    set_error("index has 2^40 suffixes or more");
+    hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
+    return -4;
+  }
+  {
+    // text-jump tables; sa_full still holds plain positions here (rows never claimed keep run 0 = their
+    // position with no run bits; rows holding kNoPosition keep it)
+    unsigned long long* row_tab = nullptr;
+    uint32_t* textrc = nullptr;
+    const uint64_t n_words = (raw.n - 1 + 15) / 16 + 4;  // padded: the comparison reads up to 3 words ahead
+    if (int rc = dev_alloc(ix, &row_tab, raw.n)) return rc;
+    if (int rc = dev_alloc(ix, &textrc, n_words)) return rc;
+    uint8_t* badpos = nullptr;
+    uint64_t* chunk_last = nullptr;
+    const uint64_t n_run_chunks = (raw.n + kRunChunk - 1) / kRunChunk;
+    SBWT_HIP(hipMalloc(&badpos, raw.n));
+    SBWT_HIP(hipMalloc(&chunk_last, n_run_chunks * sizeof(uint64_t)));
+    SBWT_HIP(hipMemset(badpos, 0, raw.n));
+    SBWT_HIP(hipMemset(row_tab, 0xff, raw.n * sizeof(uint64_t)));
+    k_row_scatter<<<grid_for(raw.n, 256), 256>>>(raw.n, sa_full, row_tab, badpos);
+    SBWT_LAUNCHED();
+    k_verify_rows<<<grid_for(raw.n, 256), 256>>>(d, sa_full, row_tab, badpos);
+    SBWT_LAUNCHED();
+    k_textrc<<<grid_for(n_words, 256), 256>>>(d, row_tab, textrc, n_words);
+    SBWT_LAUNCHED();
+    k_run_chunks<<<grid_for(n_run_chunks, 256), 256>>>(raw.n, badpos, row_tab, chunk_last);
+    k_run_scan<<<1, 1024>>>(chunk_last, n_run_chunks);
+    k_run_apply<<<grid_for(n_run_chunks, 256), 256>>>(raw.n, badpos, row_tab, chunk_last, sa_full);
+    SBWT_LAUNCHED();
+    SBWT_HIP(hipDeviceSynchronize());
+    hipFree(badpos); hipFree(chunk_last);
+    d.row_tab = reinterpret_cast<const uint64_t*>(row_tab);
+    d.textrc = textrc;
+  }
 
   k_planes2<<<grid_for(nb * 64, 256), 256>>>(d, blocks2, d_small);
   SBWT_LAUNCHED();

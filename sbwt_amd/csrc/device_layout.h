@@ -39,6 +39,12 @@ static_assert(sizeof(Block2) == 128, "Block2 is one 128-byte granule");
 constexpr int kSuperShift = 31;  // superblock = 2^31 positions, so relative counts fit 32 bits
 
 constexpr uint64_t kNoPosition = ~0ull;  // sa_full sentinel: the upstream unique-hit walk reports nothing
+// sa_full entry = text position (low 40 bits) | run (high 24 bits, saturating): the number of consecutive text
+// positions p, p-1, ..., p-run+1 whose rows are LF-consistent (see device_index.hip, k_verify_rows), i.e. how far
+// a size-1 interval can be carried by text comparison instead of rank queries.
+constexpr int kPosBits = 40;
+constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
+constexpr uint64_t kRunMax = (1ull << (64 - kPosBits)) - 1;
 
 // Everything the kernels need, passed by value.
 struct DeviceIndex {
@@ -56,7 +62,9 @@ struct DeviceIndex {
   const Block2* blocks2;
   const uint64_t* sb_abs;   // [n_super][16]: K2[code] + #code before the superblock
   const uint64_t* loc_vals; // SA value of the k-th sampled position (location_table[k].second)
-  const uint64_t* sa_full;  // memoised unique-hit locate: result of the upstream walk started at i
+  const uint64_t* sa_full;  // memoised unique-hit locate: result of the upstream walk started at i (+ run, see above)
+  const uint64_t* row_tab;  // inverse of sa_full: row whose walk reports text position p (n entries, ~0 = none)
+  const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row_tab[n-1-x]]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;
   const uint64_t* npos_key; const uint64_t* npos_val; uint32_t n_npos;

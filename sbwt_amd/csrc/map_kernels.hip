@@ -56,6 +56,20 @@ __device__ __forceinline__ void shift128(uint4& w, const int s) {
   w.w >>= s;
 }
 
+// 32 bases (64 bits) of a 2-bit packed array starting at base `pos`
+__device__ __forceinline__ uint64_t funnel64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh) {
+  const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
+  return sh ? ((lo >> sh) | ((uint64_t)w2 << (64 - sh))) : lo;
+}
+__device__ __forceinline__ uint64_t text_bits64(const uint32_t* __restrict__ t, uint64_t pos) {
+  const uint64_t wi = pos >> 4;  // textrc is padded by 4 words
+  return funnel64(t[wi], t[wi + 1], t[wi + 2], 2u * (uint32_t)(pos & 15));
+}
+__device__ __forceinline__ uint64_t read_bits64(const uint32_t* __restrict__ rp, uint32_t wpr, uint32_t pos) {
+  const uint32_t wi = pos >> 4;  // never reads past the read's own record
+  return funnel64(rp[wi], wi + 1 < wpr ? rp[wi + 1] : 0u, wi + 2 < wpr ? rp[wi + 2] : 0u, 2u * (pos & 15u));
+}
+
 // rank2 for one end of the interval from one Block2: K2[code] + #{j < i : code(j) == code}
 struct Step2 {
   uint64_t mask;  // positions of the block whose code matches
@@ -108,7 +122,8 @@ __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapA
   if (r >= a.n_reads) return;  // both lanes of a pair leave together
   const uint32_t L = a.lens[r];
   const uint32_t* rp = a.packed + r * (uint64_t)a.wpr;
-  uint64_t lo = 0, hi = 0;
+  uint64_t lo = 0, hi = 0, located = 0;
+  bool have_located = false;
   uint32_t flags = 0;
   if (L < (uint32_t)kKmer || L > a.wpr * 16u) {
     flags = kFlagInvalid;
@@ -124,7 +139,56 @@ __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapA
     hi = sub ? mine : theirs;
     shift128(w, 24);
     uint32_t j = kKmer;
-    while (j + 1 < L && lo < hi) {
+    bool tried_jump = false;
+    while (j < L && lo < hi) {
+      if (hi - lo == 1 && !tried_jump) {
+        // A size-1 interval follows the LF chain of its row; where the tables are LF-consistent (run, see
+        // device_layout.h) the remaining r bases are compared with the text instead of ranked one by one.
+        tried_jump = true;
+        const uint64_t e = ix.sa_full[lo];
+        const uint64_t p = e & kPosMask, run = e >> kPosBits;
+        const uint32_t r = L - j;
+        if (e != kNoPosition && run > (uint64_t)r && p >= (uint64_t)r) {
+          const uint64_t x0 = ix.n - 1 - p;  // read[j + t] continues the match iff it equals textrc[x0 + t]
+          uint32_t t = 0;
+          bool mismatch = false;
+          while (t < r) {
+            const uint32_t nb = r - t < 32u ? r - t : 32u;
+            uint64_t d = read_bits64(rp, a.wpr, j + t) ^ text_bits64(ix.textrc, x0 + t);
+            if (nb < 32u) d &= (1ull << (2 * nb)) - 1ull;
+            if (d) {
+              t += (uint32_t)(__ffsll((unsigned long long)d) - 1) >> 1;
+              mismatch = true;
+              break;
+            }
+            t += nb;
+          }
+          if (!mismatch) {
+            lo = ix.row_tab[p - r];
+            hi = lo + 1;
+            located = p - r;
+            have_located = true;
+          } else {
+            // the chain dies at base j + t: exec_exact_match on the row reached after t matching bases
+            const uint64_t it = t ? ix.row_tab[p - t] : lo;
+            const uint32_t c = ((rp[(j + t) >> 4] >> (2 * ((j + t) & 15u))) & 3u) ^ 3u;
+            lo = lf1(ix, it, c);
+            hi = lf1(ix, it + 1, c);
+          }
+          j = L;
+          break;
+        }
+      }
+      if (j + 1 == L) {  // last base alone
+        if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
+        const uint32_t c = (w.x & 3u) ^ 3u;
+        const uint64_t v1 = lf1(ix, sub ? hi : lo, c);
+        const uint64_t w1 = pair_swap64(v1);
+        lo = sub ? w1 : v1;
+        hi = sub ? v1 : w1;
+        j += 1;
+        break;
+      }
       if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
       const uint32_t two = (w.x & 15u) ^ 15u;          // complement of read[j], read[j+1]
       const uint32_t code = ((two & 3u) << 2) | (two >> 2);  // x = first prepended base, y = second
@@ -134,7 +198,7 @@ __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapA
       const Step2 s1 = load_step2(ix, b_lo, code, sub);
       const uint32_t o1 = sub ? (uint32_t)(hi - (b_lo << 6)) : (uint32_t)(lo & 63);
       uint64_t val = s1.base + (uint64_t)__popcll(s1.mask & below(o1));
-      if (__ballot(!same)) {  // wave-uniform: only the first steps of a read have ends in different blocks
+      if (__ballot(!same)) {  // only the first steps of a read have ends in different blocks
         const Step2 s2 = load_step2(ix, hi >> 6, code, sub);
         const uint64_t v2 = s2.base + (uint64_t)__popcll(s2.mask & below((uint32_t)(hi & 63)));
         if (sub && !same) val = v2;
@@ -156,14 +220,6 @@ __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapA
       j += 2;
       shift128(w, 4);
     }
-    if (j + 1 == L && lo < hi) {  // odd number of steps: last base alone
-      if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
-      const uint32_t c = (w.x & 3u) ^ 3u;
-      const uint64_t v1 = lf1(ix, sub ? hi : lo, c);
-      const uint64_t w1 = pair_swap64(v1);
-      lo = sub ? w1 : v1;
-      hi = sub ? v1 : w1;
-    }
   }
 
   int32_t nh = 0;
@@ -173,8 +229,10 @@ __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapA
     if (m > a.limit) {
       flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
     } else if (m == 1) {
-      const uint64_t p0 = ix.sa_full[lo];
-      if (p0 != kNoPosition) {
+      // the text comparison already knows the position; otherwise one gather of the memoised locate
+      const uint64_t e0 = have_located ? located : ix.sa_full[lo];
+      const uint64_t p0 = e0 & kPosMask;
+      if (e0 != kNoPosition) {
         // push_position (searcher.hpp:504-539); the pair splits the two ends of the alignment
         uint64_t position = p0;
         bool is_rc = false;

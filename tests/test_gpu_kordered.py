@@ -1,0 +1,123 @@
+"""GPU: parity on indexes whose suffix order is only k-ordered (ties beyond k bases in arbitrary order).
+
+The upstream sort stops at sort_len bases and leaves tied suffixes in whatever order the quicksort produced
+(PSEUDO_DCS_FOR_SBWT::compare == true, difference_cover.hpp:30-41), so on such an index the LF mapping is not
+the suffix-array permutation inside tie groups.  The mapper's text-comparison shortcut is only valid where the
+tables are LF-consistent; everywhere else it must fall back to rank queries.  Parity here is GPU vs the oracle on
+the SAME tables (built in numpy from a deliberately tie-shuffled suffix order), which is what "bit-exact with
+the reference on the same index" means for an index no test fixture of the reference covers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+def tables_from_order(text, sa, interval=64):
+    """reference-format tables for text (ending in '$') and a suffix ORDER sa (any permutation)"""
+    n = len(text)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "$": 0}
+    bwt = np.array([code[text[s - 1]] if s else 0 for s in sa], dtype=np.uint8)
+    first_location = int(np.nonzero(np.asarray(sa) == 0)[0][0])
+    occ_len = n // interval + 1
+    occ = np.zeros((4, occ_len), dtype=np.uint64)
+    for c in range(4):
+        cum = np.concatenate([[0], np.cumsum(bwt == c)])
+        occ[c] = cum[np.arange(occ_len) * interval]
+    fbwt = (np.asarray(sa, dtype=np.uint64) % interval).astype(np.uint8)
+    rows = np.nonzero(fbwt == 0)[0]
+    loc = np.stack([rows.astype(np.uint64), np.asarray(sa, dtype=np.uint64)[rows]], axis=1).reshape(-1)
+    pad = (-n) % 4
+    b4 = np.concatenate([bwt, np.zeros(pad + 4, np.uint8)])[: (n // 4 + 1) * 4].reshape(-1, 4)
+    jbwt = (b4[:, 0] << 6 | b4[:, 1] << 4 | b4[:, 2] << 2 | b4[:, 3]).astype(np.uint8)
+    counts = [sum(1 for ch in text[:-1] if ch == b) for b in "ACGT"]
+    c4 = np.array([1, 1 + counts[0], 1 + counts[0] + counts[1], 1 + counts[0] + counts[1] + counts[2]], dtype=np.uint64)
+    # c_functions: first SA index of every 12-mer that has 12 real bases; '$' suffix defines code 0
+    K = 4 ** 12
+    starts = np.full(K + 1, np.iinfo(np.uint64).max, dtype=np.uint64)
+    starts[K] = n
+    m = n - 1
+    for i, s in enumerate(sa):
+        if s == m:
+            kc = 0
+        elif s + 12 <= m:
+            kc = 0
+            for ch in text[s:s + 12]:
+                kc = kc * 4 + code[ch]
+        else:
+            continue
+        if starts[kc] > i:
+            starts[kc] = i
+    cfs = np.minimum.accumulate(starts[::-1])[::-1].copy()
+    return dict(interval=interval, n=n, first_location=first_location, c4=c4, cfs=cfs, occ=occ, jbwt=jbwt, fbwt=fbwt,
+                loc=loc, occ_len=occ_len)
+
+
+def genome(golden_dir):
+    chroms = []
+    for line in open(os.path.join(golden_dir, "g2.fa")):
+        if line.startswith(">"):
+            chroms.append("")
+        else:
+            chroms[-1] += line.strip().upper()
+    fwd = "".join(c.replace("N", "") for c in chroms)
+    return chroms, fwd
+
+
+@pytest.mark.parametrize("k,seed", [(1000, 0), (40, 1), (20, 2), (13, 3)])
+def test_tie_shuffled_index_matches_oracle(golden_dir, oracle, k, seed):
+    import sbwt_amd as sb
+    chroms, fwd = genome(golden_dir)
+    text = fwd + fwd.translate(COMP)[::-1] + "$"
+    n = len(text)
+    rng = np.random.default_rng(seed)
+    tie = rng.permutation(n)
+    sa = sorted(range(n), key=lambda i: (text[i:i + k], int(tie[i])))   # k-ordered, ties in random order
+    T = tables_from_order(text, sa)
+    chr_start = np.array([0, len(chroms[0].replace("N", ""))], dtype=np.uint64)
+    npos_key = np.array([0, 3600, 3720, 6820], dtype=np.uint64)       # golden.json g2 ref_npos_map
+    npos_val = np.array([0, 10, 5, 5], dtype=np.uint64)
+    ix = sb.Index.from_tables(0, T["interval"], T["n"], T["first_location"], len(fwd), T["c4"], T["cfs"],
+                              [T["occ"][c] for c in range(4)], T["jbwt"], T["fbwt"], T["loc"], chr_start, npos_key,
+                              npos_val, chr_names=["chr1", "chr2"])
+    L = oracle.lib()
+    occs = [np.ascontiguousarray(T["occ"][c]) for c in range(4)]
+    h = L.sbo_index_wrap(T["interval"], T["n"], T["first_location"], len(fwd), T["c4"].ctypes.data,
+                         T["cfs"].ctypes.data, occs[0].ctypes.data, occs[1].ctypes.data, occs[2].ctypes.data,
+                         occs[3].ctypes.data, T["occ_len"], T["jbwt"].ctypes.data, T["fbwt"].ctypes.data,
+                         T["loc"].ctypes.data, T["loc"].size // 2, 2, chr_start.ctypes.data, 4, npos_key.ctypes.data,
+                         npos_val.ctypes.data)
+    oix = oracle.OracleIndex(h, keep=(T, occs, chr_start, npos_key, npos_val))
+    reads = []
+    seq = fwd
+    for Lr in list(range(12, 34)) + [40, 50, 64, 65, 100, 101, 150, 200]:
+        for _ in range(60):
+            p = int(rng.integers(0, len(seq) - Lr))
+            s = seq[p:p + Lr]
+            if rng.random() < 0.5:
+                s = s.translate(COMP)[::-1]
+            if rng.random() < 0.3:
+                q = int(rng.integers(0, Lr))
+                s = s[:q] + "ACGT"[int(rng.integers(0, 4))] + s[q + 1:]
+            reads.append(s)
+    rep = chroms[0][1000:1300]                                          # the 300-bp repeat: tie groups live here
+    for a, b in ((0, 12), (0, 100), (5, 90), (100, 160), (150, 300), (280, 300), (0, 300), (20, 290)):
+        reads += [rep[a:b], rep[a:b].translate(COMP)[::-1]]
+    reads += [text[:40], text[:13], fwd[-30:], "A" * 20, "T" * 15]
+    packed, lens = sb.pack_reads(reads)
+    ctx = sb.Context(ix, len(reads))
+    res, hits = ctx.map_batch(packed, lens)
+    lo, hi, nh, first, ohits = oix.map_batch(reads)
+    np.testing.assert_array_equal(res["sa_lo"], lo)
+    np.testing.assert_array_equal(res["sa_hi"], hi)
+    np.testing.assert_array_equal(res["nh"], nh)
+    for r in np.nonzero(nh)[0]:
+        a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
+        assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d" % r
+    assert (nh > 0).sum() > len(reads) // 3
+    ctx.close(); ix.close(); oix.close()
