@@ -4,10 +4,11 @@
 // (init_exact_match :83-96), backward search (exec_exact_match :102-105, two rank queries per base),
 // suppression test (:415), locate (level-0 scan :424-443 + find_possible :460-503), push_position
 // filters (:504-539).  Here:
-//   k_search : two lanes per read.  One 128-byte Block2 access advances BOTH ends of the SA interval by
-//              TWO bases; the pair splits the four bit planes (16 B per lane) and each lane finishes
-//              one end of the interval.  Unique hits are located by one 8-byte gather of sa_full and
-//              filtered in place; multi-hit reads are queued.
+//   k_search : one lane per read.  One 128-byte Block2 access advances BOTH ends of the SA interval by TWO
+//              bases.  As soon as the interval is a single row, the rest of the read is compared with the
+//              text the tables imply (textrc) and the final row comes from row_tab -- the same arithmetic
+//              as the remaining rank queries wherever the tables are LF-consistent (sa_full's run field),
+//              rank queries elsewhere.  Unique hits are filtered in place; multi-hit reads are queued.
 //   k_multi  : the upstream depth-first locate, statement for statement, for the queued reads.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -49,13 +50,6 @@ struct Frame {  // one activation of find_possible
 
 constexpr uint32_t kFlagInvalid = 0x80000000u;  // read shorter than 12 or longer than its record (never from sbwt_pack_reads)
 
-__device__ __forceinline__ void shift128(uint4& w, const int s) {
-  w.x = __builtin_amdgcn_alignbit(w.y, w.x, s);
-  w.y = __builtin_amdgcn_alignbit(w.z, w.y, s);
-  w.z = __builtin_amdgcn_alignbit(w.w, w.z, s);
-  w.w >>= s;
-}
-
 // 32 bases (64 bits) of a 2-bit packed array starting at base `pos`
 __device__ __forceinline__ uint64_t funnel64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh) {
   const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
@@ -70,28 +64,57 @@ __device__ __forceinline__ uint64_t read_bits64(const uint32_t* __restrict__ rp,
   return funnel64(rp[wi], wi + 1 < wpr ? rp[wi + 1] : 0u, wi + 2 < wpr ? rp[wi + 2] : 0u, 2u * (pos & 15u));
 }
 
-// rank2 for one end of the interval from one Block2: K2[code] + #{j < i : code(j) == code}
+// One Block2 as seen by one read: positions whose code matches, and the count before the block
+// (K2[code] + superblock absolute + block relative).  rank2(code, i) = base + popcount(mask & below(i & 63)).
 struct Step2 {
-  uint64_t mask;  // positions of the block whose code matches
-  uint64_t base;  // superblock absolute + block relative count
+  uint64_t mask;
+  uint64_t base;
 };
-__device__ __forceinline__ Step2 load_step2(const DeviceIndex& ix, uint64_t blk, uint32_t code, uint32_t sub) {
+__device__ __forceinline__ Step2 load_step2(const DeviceIndex& ix, uint64_t blk, uint32_t code) {
   const Block2* b = ix.blocks2 + blk;
-  // lane 0 of the pair reads planes 0,1 (bits of y), lane 1 planes 2,3 (bits of x): 16 bytes each, one line
-  const uint4 pl = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(b) + 16 * sub);
+  const uint4 p01 = *reinterpret_cast<const uint4*>(&b->plane[0]);  // bits of y
+  const uint4 p23 = *reinterpret_cast<const uint4*>(&b->plane[2]);  // bits of x
   const uint32_t cn = b->cnt[code];
   const uint64_t sb = ix.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code];
-  const uint64_t pa = ((uint64_t)pl.y << 32) | pl.x, pb = ((uint64_t)pl.w << 32) | pl.z;
-  const uint32_t kb = code >> (2 * sub);
-  const uint64_t part = ((kb & 1) ? pa : ~pa) & ((kb & 2) ? pb : ~pb);
+  const uint64_t q0 = ((uint64_t)p01.y << 32) | p01.x, q1 = ((uint64_t)p01.w << 32) | p01.z;
+  const uint64_t q2 = ((uint64_t)p23.y << 32) | p23.x, q3 = ((uint64_t)p23.w << 32) | p23.z;
   Step2 s;
-  s.mask = part & pair_swap64(part);
+  s.mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
   s.base = sb + cn;
   return s;
 }
 __device__ __forceinline__ uint64_t rank2_correction(const DeviceIndex& ix, uint32_t code, uint64_t i) {
   return (uint64_t)(ix.special_pos[0] < i && code == ix.special_code[0]) +
          (uint64_t)(ix.special_pos[1] < i && code == ix.special_code[1]);
+}
+
+// exec_exact_match (searcher.hpp:102-105) for the two bases read[j], read[j+1] at once; `two` = their packed codes.
+// Returns false when the interval died: lo/hi then hold what the upstream loop stops with (it stops after the
+// FIRST base if that one already emptied the interval, searcher.hpp:406, so that base is replayed alone).
+__device__ __forceinline__ bool step_two_bases(const DeviceIndex& ix, uint32_t two, uint64_t& lo, uint64_t& hi) {
+  two ^= 15u;                                            // complement: the query is RC(read)
+  const uint32_t code = ((two & 3u) << 2) | (two >> 2);  // x = first prepended base, y = second
+  const uint64_t b_lo = lo >> 6;
+  const bool same = ((hi - 1) >> 6) == b_lo;             // both ends in one block: one access serves both
+  const Step2 s1 = load_step2(ix, b_lo, code);
+  uint64_t nlo = s1.base + (uint64_t)__popcll(s1.mask & below((uint32_t)(lo & 63)));
+  uint64_t nhi;
+  if (same) {
+    nhi = s1.base + (uint64_t)__popcll(s1.mask & below((uint32_t)(hi - (b_lo << 6))));
+  } else {
+    const Step2 s2 = load_step2(ix, hi >> 6, code);
+    nhi = s2.base + (uint64_t)__popcll(s2.mask & below((uint32_t)(hi & 63)));
+  }
+  nlo -= rank2_correction(ix, code, lo);
+  nhi -= rank2_correction(ix, code, hi);
+  if (nlo >= nhi) {
+    const uint64_t l1 = lf1(ix, lo, code >> 2), h1 = lf1(ix, hi, code >> 2);
+    if (l1 >= h1) { lo = l1; hi = h1; } else { lo = nlo; hi = nhi; }
+    return false;
+  }
+  lo = nlo;
+  hi = nhi;
+  return true;
 }
 
 // searcher.hpp:504-539 for one lane
@@ -115,185 +138,162 @@ __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64
   return true;
 }
 
+// Phases, chosen so that the lanes of a wave wait on memory together (the walk is latency-bound: throughput is
+// requests in flight over latency, and a lane that idles while its neighbours take a private branch is lost):
+//   1. 12-mer table, then two-base steps while ANY read of the wave still has an interval wider than 1;
+//   2. every read whose interval is one row: sa_full -> (text position, run) -> compare the rest of the read
+//      with the text and fetch the final row, all loads issued together;
+//   3. leftovers (repeats, reads near an LF-inconsistent row or the text start): two-base steps to the end;
+//   4. suppression test, unique-hit position filters (push_position), hit slot, result record.
+constexpr int kNarrowIters = 6;
+
 __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapArgs a) {
-  const uint64_t tid = global_thread();
-  const uint64_t r = tid >> 1;
-  const uint32_t sub = (uint32_t)(tid & 1);
-  if (r >= a.n_reads) return;  // both lanes of a pair leave together
+  const uint64_t r = global_thread();
+  if (r >= a.n_reads) return;
   const uint32_t L = a.lens[r];
   const uint32_t* rp = a.packed + r * (uint64_t)a.wpr;
   uint64_t lo = 0, hi = 0, located = 0;
   bool have_located = false;
   uint32_t flags = 0;
+  uint32_t j = kKmer;
+  bool alive = true;  // false once the interval died (lo/hi final)
   if (L < (uint32_t)kKmer || L > a.wpr * 16u) {
     flags = kFlagInvalid;
-  } else {
-    // bases 0..63; base j sits at bits 2j.  The upstream query is RC(read): walking it from its end is
-    // walking the read from its start with every base complemented (code ^ 3).
-    uint4 w = *reinterpret_cast<const uint4*>(rp);
+    alive = false;
+    j = L;
+  }
+  // bases 0..63; base j sits at bits 2j.  The upstream query is RC(read): walking it from its end is walking
+  // the read from its start with every base complemented (code ^ 3).
+  const uint4 w = *reinterpret_cast<const uint4*>(rp);
+  const uint64_t w_lo = ((uint64_t)w.y << 32) | w.x;  // bases 0..31
+  if (alive) {
     // init_exact_match (searcher.hpp:83-96): sum_k q[L-12+k] * 4^(11-k) with q[L-12+k] = 3 - read[11-k]
     const uint32_t kmer = (~w.x) & 0xFFFFFFu;
-    const uint64_t mine = ix.c_functions[kmer + sub];
-    const uint64_t theirs = pair_swap64(mine);
-    lo = sub ? theirs : mine;
-    hi = sub ? mine : theirs;
-    shift128(w, 24);
-    uint32_t j = kKmer;
-    bool tried_jump = false;
-    while (j < L && lo < hi) {
-      if (hi - lo == 1 && !tried_jump) {
-        // A size-1 interval follows the LF chain of its row; where the tables are LF-consistent (run, see
-        // device_layout.h) the remaining r bases are compared with the text instead of ranked one by one.
-        tried_jump = true;
-        const uint64_t e = ix.sa_full[lo];
-        const uint64_t p = e & kPosMask, run = e >> kPosBits;
-        const uint32_t r = L - j;
-        if (e != kNoPosition && run > (uint64_t)r && p >= (uint64_t)r) {
-          const uint64_t x0 = ix.n - 1 - p;  // read[j + t] continues the match iff it equals textrc[x0 + t]
-          uint32_t t = 0;
-          bool mismatch = false;
-          while (t < r) {
-            const uint32_t nb = r - t < 32u ? r - t : 32u;
-            uint64_t d = read_bits64(rp, a.wpr, j + t) ^ text_bits64(ix.textrc, x0 + t);
-            if (nb < 32u) d &= (1ull << (2 * nb)) - 1ull;
-            if (d) {
-              t += (uint32_t)(__ffsll((unsigned long long)d) - 1) >> 1;
-              mismatch = true;
-              break;
-            }
-            t += nb;
+    lo = ix.c_functions[kmer];
+    hi = ix.c_functions[kmer + 1];
+    alive = lo < hi;
+  }
+  // ---- phase 1 (j stays below 32: bases come from w_lo)
+#pragma unroll 1
+  for (int it = 0; it < kNarrowIters; ++it) {
+    const bool act = alive && hi - lo > 1 && j + 1 < L;
+    if (!__any(act)) break;
+    if (act) {
+      alive = step_two_bases(ix, (uint32_t)(w_lo >> (2 * j)) & 15u, lo, hi);
+      if (alive) j += 2;
+    }
+  }
+  // ---- phase 2
+  if (alive && hi - lo == 1 && j < L) {
+    const uint64_t e = ix.sa_full[lo];
+    const uint64_t p = e & kPosMask, run = e >> kPosBits;
+    const uint32_t rem = L - j;
+    if (e != kNoPosition && run > (uint64_t)rem && p >= (uint64_t)rem) {
+      const uint64_t x0 = ix.n - 1 - p;            // read[j + t] continues the match iff it equals textrc[x0 + t]
+      const uint64_t row_end = ix.row_tab[p - rem];  // needed unless a base differs; fetched alongside the text
+      uint64_t d0 = read_bits64(rp, a.wpr, j) ^ text_bits64(ix.textrc, x0);
+      uint64_t d1 = 0;
+      if (rem > 32u) d1 = read_bits64(rp, a.wpr, j + 32u) ^ text_bits64(ix.textrc, x0 + 32u);
+      if (rem < 32u) d0 &= (1ull << (2 * rem)) - 1ull;
+      if (rem < 64u && rem > 32u) d1 &= (1ull << (2 * (rem - 32u))) - 1ull;
+      uint32_t t = rem;  // first differing base, rem = none
+      if (d0) t = (uint32_t)(__ffsll((unsigned long long)d0) - 1) >> 1;
+      else if (d1) t = 32u + ((uint32_t)(__ffsll((unsigned long long)d1) - 1) >> 1);
+      else {
+        for (uint32_t u = 64u; u < rem; u += 32u) {  // reads longer than 64 + j bases
+          const uint32_t nb = rem - u < 32u ? rem - u : 32u;
+          uint64_t d = read_bits64(rp, a.wpr, j + u) ^ text_bits64(ix.textrc, x0 + u);
+          if (nb < 32u) d &= (1ull << (2 * nb)) - 1ull;
+          if (d) {
+            t = u + ((uint32_t)(__ffsll((unsigned long long)d) - 1) >> 1);
+            break;
           }
-          if (!mismatch) {
-            lo = ix.row_tab[p - r];
-            hi = lo + 1;
-            located = p - r;
-            have_located = true;
-          } else {
-            // the chain dies at base j + t: exec_exact_match on the row reached after t matching bases
-            const uint64_t it = t ? ix.row_tab[p - t] : lo;
-            const uint32_t c = ((rp[(j + t) >> 4] >> (2 * ((j + t) & 15u))) & 3u) ^ 3u;
-            lo = lf1(ix, it, c);
-            hi = lf1(ix, it + 1, c);
-          }
-          j = L;
-          break;
         }
       }
-      if (j + 1 == L) {  // last base alone
-        if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
-        const uint32_t c = (w.x & 3u) ^ 3u;
-        const uint64_t v1 = lf1(ix, sub ? hi : lo, c);
-        const uint64_t w1 = pair_swap64(v1);
-        lo = sub ? w1 : v1;
-        hi = sub ? v1 : w1;
-        j += 1;
-        break;
+      if (t == rem) {
+        lo = row_end;
+        hi = lo + 1;
+        located = p - rem;
+        have_located = true;
+      } else {
+        // the chain dies at base j + t: exec_exact_match on the row reached after t matching bases
+        const uint64_t it = t ? ix.row_tab[p - t] : lo;
+        const uint32_t c = ((rp[(j + t) >> 4] >> (2 * ((j + t) & 15u))) & 3u) ^ 3u;
+        lo = lf1(ix, it, c);
+        hi = lf1(ix, it + 1, c);
+        alive = false;
       }
-      if ((j & 63u) == 0) w = *reinterpret_cast<const uint4*>(rp + (j >> 4));
-      const uint32_t two = (w.x & 15u) ^ 15u;          // complement of read[j], read[j+1]
-      const uint32_t code = ((two & 3u) << 2) | (two >> 2);  // x = first prepended base, y = second
-      const uint64_t b_lo = lo >> 6;
-      const bool same = ((hi - 1) >> 6) == b_lo;
-      const uint64_t my_i = sub ? hi : lo;
-      const Step2 s1 = load_step2(ix, b_lo, code, sub);
-      const uint32_t o1 = sub ? (uint32_t)(hi - (b_lo << 6)) : (uint32_t)(lo & 63);
-      uint64_t val = s1.base + (uint64_t)__popcll(s1.mask & below(o1));
-      if (__ballot(!same)) {  // only the first steps of a read have ends in different blocks
-        const Step2 s2 = load_step2(ix, hi >> 6, code, sub);
-        const uint64_t v2 = s2.base + (uint64_t)__popcll(s2.mask & below((uint32_t)(hi & 63)));
-        if (sub && !same) val = v2;
-      }
-      val -= rank2_correction(ix, code, my_i);
-      const uint64_t other = pair_swap64(val);
-      const uint64_t nlo = sub ? other : val, nhi = sub ? val : other;
-      if (nlo >= nhi) {
-        // The interval died inside this pair of bases.  Upstream stops after the FIRST base if that one
-        // already emptied it (loop condition lo < hi, searcher.hpp:406), so replay that base alone.
-        const uint64_t v1 = lf1(ix, my_i, code >> 2);
-        const uint64_t w1 = pair_swap64(v1);
-        const uint64_t l1 = sub ? w1 : v1, h1 = sub ? v1 : w1;
-        if (l1 >= h1) { lo = l1; hi = h1; } else { lo = nlo; hi = nhi; }
-        break;
-      }
-      lo = nlo;
-      hi = nhi;
-      j += 2;
-      shift128(w, 4);
+      j = L;
+    }
+  }
+  // ---- phase 3
+  while (alive && j < L) {
+    if (j + 1 == L) {  // last base alone
+      const uint32_t c = ((rp[j >> 4] >> (2 * (j & 15u))) & 3u) ^ 3u;
+      const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
+      lo = l1;
+      hi = h1;
+      alive = lo < hi;
+      j += 1;
+    } else {
+      alive = step_two_bases(ix, (rp[j >> 4] >> (2 * (j & 15u))) & 15u, lo, hi);  // j is even: one word
+      if (alive) j += 2;
     }
   }
 
+  // ---- phase 4
   int32_t nh = 0;
   uint64_t first_hit = 0;
-  if (hi > lo) {
-    const uint64_t m = hi - lo;
-    if (m > a.limit) {
-      flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
-    } else if (m == 1) {
-      // the text comparison already knows the position; otherwise one gather of the memoised locate
-      const uint64_t e0 = have_located ? located : ix.sa_full[lo];
-      const uint64_t p0 = e0 & kPosMask;
-      if (e0 != kNoPosition) {
-        // push_position (searcher.hpp:504-539); the pair splits the two ends of the alignment
-        uint64_t position = p0;
-        bool is_rc = false;
-        if (position >= ix.real_size) {
-          is_rc = true;
-          position = ix.real_size * 2 - position - L;
+  bool unique_ok = false;
+  sbwt_hit h;
+  const uint64_t m = hi > lo ? hi - lo : 0;
+  if (m > a.limit) {
+    flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
+  } else if (m == 1) {
+    // the text comparison already knows the position; otherwise one gather of the memoised locate
+    const uint64_t e0 = have_located ? located : ix.sa_full[lo];
+    if (e0 != kNoPosition) unique_ok = push_position_lane(ix, e0 & kPosMask, L, a.strand, &h);
+  }
+  {
+    // one slot in hits[] per surviving unique hit, handed out with one atomic per wave
+    const uint64_t wmask = __ballot(unique_ok);
+    if (wmask) {
+      const uint32_t lane = threadIdx.x & 63;
+      const int leader = __ffsll((unsigned long long)wmask) - 1;
+      unsigned long long base = 0;
+      if ((int)lane == leader) base = atomicAdd(&a.ctr->hit_count, (unsigned long long)__popcll(wmask));
+      base = ((unsigned long long)__shfl((int)(base >> 32), leader) << 32) |
+             (unsigned int)__shfl((int)(base & 0xffffffffu), leader);
+      if (unique_ok) {
+        const uint64_t slot = base + (uint64_t)__popcll(wmask & ((1ull << lane) - 1));
+        if (slot < a.hits_cap) {
+          a.hits[slot] = h;
+          first_hit = slot;
+          nh = 1;
+        } else {
+          atomicOr(&a.ctr->overflow, 1u);
         }
-        bool ok = !((a.strand == 0 && !is_rc) || (a.strand == 1 && is_rc));
-        if (ok) {
-          const uint64_t q = position + (sub ? (uint64_t)L - 1 : 0);
-          const uint32_t ci = upper_bound_minus1(ix.chr_start, ix.n_chr, q);
-          const uint32_t ni = upper_bound_minus1(ix.npos_key, ix.n_npos, q);
-          ok = (ci == pair_swap(ci)) && (ni == pair_swap(ni));
-          if (ok) {
-            // one slot in hits[], handed out with one atomic per wave
-            const bool writer = sub == 0;
-            const uint64_t wmask = __ballot(writer);
-            const uint32_t lane = threadIdx.x & 63;
-            const int leader = __ffsll((unsigned long long)wmask) - 1;
-            unsigned long long base = 0;
-            if ((int)lane == leader) base = atomicAdd(&a.ctr->hit_count, (unsigned long long)__popcll(wmask));
-            base = ((unsigned long long)__shfl((int)(base >> 32), leader) << 32) |
-                   (unsigned int)__shfl((int)(base & 0xffffffffu), leader);
-            if (writer) {
-              const uint64_t slot = base + (uint64_t)__popcll(wmask & ((1ull << lane) - 1));
-              if (slot < a.hits_cap) {
-                sbwt_hit h;
-                h.pos0 = position - ix.chr_start[ci] + ix.npos_val[ni];
-                h.chr_id = ci;
-                h.is_rc = is_rc ? 1u : 0u;
-                a.hits[slot] = h;
-                first_hit = slot;
-                nh = 1;
-              } else {
-                atomicOr(&a.ctr->overflow, 1u);
-              }
-            }
-          }
-        }
-      }
-    } else if (sub == 0) {
-      // multi-hit read: reserve m slots and hand the read to k_multi
-      const uint64_t slot = atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
-      if (slot + m <= a.hits_cap) {
-        first_hit = slot;
-        const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
-        a.multi_queue[q] = (uint32_t)r;
-      } else {
-        atomicOr(&a.ctr->overflow, 1u);
       }
     }
   }
-  if (sub == 0) {
-    sbwt_read_result res;
-    res.sa_lo = lo;
-    res.sa_hi = hi;
-    res.first_hit = first_hit;
-    res.nh = nh;
-    res.flags = flags;
-    a.results[r] = res;
+  if (m > 1 && m <= a.limit) {
+    // multi-hit read: reserve m slots and hand the read to k_multi
+    const uint64_t slot = atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
+    if (slot + m <= a.hits_cap) {
+      first_hit = slot;
+      const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
+      a.multi_queue[q] = (uint32_t)r;
+    } else {
+      atomicOr(&a.ctr->overflow, 1u);
+    }
   }
+  sbwt_read_result res;
+  res.sa_lo = lo;
+  res.sa_hi = hi;
+  res.first_hit = first_hit;
+  res.nh = nh;
+  res.flags = flags;
+  a.results[r] = res;
 }
 
 // ---- multi-hit locate: the upstream DFS, one lane per queued read -----------------------------
@@ -481,7 +481,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   a.multi_queue = c->d_queue;
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
-  k_search<<<grid_items(n_reads * 2, 256), 256, 0, c->stream>>>(c->ix->d, a);
+  k_search<<<grid_items(n_reads, 256), 256, 0, c->stream>>>(c->ix->d, a);
   SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
   k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(c->ix->d, a, c->d_stacks, c->multi_lanes);
