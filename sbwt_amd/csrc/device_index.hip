@@ -2,6 +2,7 @@
 // device_layout.h.  One-time work per index; correctness first, all kernels are plain gfx950 HIP.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "index_impl.hpp"
@@ -387,6 +388,23 @@ __global__ __launch_bounds__(256) void k_apply2(Block2* __restrict__ blocks, uin
   }
 }
 
+// ---- kmer_tab: memoised search prefix -------------------------------------------------------------------
+// entry v (the complemented codes of read[0..K), base t at bits 2t) = the interval the upstream search holds after
+// init_exact_match on the first 12 bases (searcher.hpp:83-96) and exec_exact_match on the next K - 12
+// (searcher.hpp:406-410, which stops as soon as the interval is empty): computed by running exactly those steps.
+__global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab) {
+  const uint64_t v = global_thread();
+  if (v >> (2 * K)) return;
+  const uint32_t kmer = (uint32_t)v & 0xFFFFFFu;
+  uint64_t lo = ix.c_functions[kmer], hi = ix.c_functions[kmer + 1];
+  bool alive = lo < hi;
+  for (uint32_t t = kKmer; alive && t < K; t += 2)
+    alive = step_two_bases(ix, ((uint32_t)(v >> (2 * t)) & 15u) ^ 15u, lo, hi);
+  uint64_t width = hi > lo ? hi - lo : 0;
+  if (width >= kKmerWide) { width = kKmerWide; lo = 0; }
+  tab[v] = lo | (width << kPosBits);
+}
+
 // ---------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t items, uint32_t per_block) { return grid_items(items, per_block); }
 
@@ -465,7 +483,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     // position with no run bits; rows holding kNoPosition keep it)
     unsigned long long* row_tab = nullptr;
     uint32_t* textrc = nullptr;
-    const uint64_t n_words = (raw.n - 1 + 15) / 16 + 4;  // padded: the comparison reads up to 3 words ahead
+    const uint64_t n_words = ((raw.n - 1 + 63) / 64) * 4 + 8;  // whole 16-byte pieces + 2 of padding: the comparison reads one piece ahead
     if (int rc = dev_alloc(ix, &row_tab, raw.n)) return rc;
     if (int rc = dev_alloc(ix, &textrc, n_words)) return rc;
     uint8_t* badpos = nullptr;
@@ -504,6 +522,25 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   d.special_code[1] = h_small[0] == ~0ull ? 0u : (uint32_t)h_small[1];
   d.blocks2 = blocks2;
   d.sb_abs = sb_abs;
+  {
+    // widest even order K <= 16 whose 4^K entries do not outnumber the suffixes (GRCh38: 16, dm6: 14, E. coli:
+    // none); SBWT_KMER_ORDER overrides (12 = none)
+    uint32_t K = kKmer;
+    while (K + 2 <= 16 && (1ull << (2 * (K + 2))) <= raw.n) K += 2;
+    if (const char* e = getenv("SBWT_KMER_ORDER")) {
+      const int want = atoi(e);
+      if (want >= kKmer && want <= 16 && (want & 1) == 0) K = (uint32_t)want;
+    }
+    d.kmer_order = K;
+    d.kmer_tab = nullptr;
+    if (K > (uint32_t)kKmer) {
+      uint64_t* tab = nullptr;
+      if (int rc = dev_alloc(ix, &tab, 1ull << (2 * K))) return rc;
+      k_kmer_table<<<grid_for(1ull << (2 * K), 256), 256>>>(d, K, tab);
+      SBWT_LAUNCHED();
+      d.kmer_tab = tab;
+    }
+  }
   SBWT_HIP(hipDeviceSynchronize());
   hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
   return 0;

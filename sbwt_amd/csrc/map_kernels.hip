@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "../../include/sbwt_amd.h"
@@ -64,78 +65,39 @@ __device__ __forceinline__ uint64_t read_bits64(const uint32_t* __restrict__ rp,
   return funnel64(rp[wi], wi + 1 < wpr ? rp[wi + 1] : 0u, wi + 2 < wpr ? rp[wi + 2] : 0u, 2u * (pos & 15u));
 }
 
-// One Block2 as seen by one read: positions whose code matches, and the count before the block
-// (K2[code] + superblock absolute + block relative).  rank2(code, i) = base + popcount(mask & below(i & 63)).
-struct Step2 {
-  uint64_t mask;
-  uint64_t base;
-};
-__device__ __forceinline__ Step2 load_step2(const DeviceIndex& ix, uint64_t blk, uint32_t code) {
-  const Block2* b = ix.blocks2 + blk;
-  const uint4 p01 = *reinterpret_cast<const uint4*>(&b->plane[0]);  // bits of y
-  const uint4 p23 = *reinterpret_cast<const uint4*>(&b->plane[2]);  // bits of x
-  const uint32_t cn = b->cnt[code];
-  const uint64_t sb = ix.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code];
-  const uint64_t q0 = ((uint64_t)p01.y << 32) | p01.x, q1 = ((uint64_t)p01.w << 32) | p01.z;
-  const uint64_t q2 = ((uint64_t)p23.y << 32) | p23.x, q3 = ((uint64_t)p23.w << 32) | p23.z;
-  Step2 s;
-  s.mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
-  s.base = sb + cn;
-  return s;
-}
-__device__ __forceinline__ uint64_t rank2_correction(const DeviceIndex& ix, uint32_t code, uint64_t i) {
-  return (uint64_t)(ix.special_pos[0] < i && code == ix.special_code[0]) +
-         (uint64_t)(ix.special_pos[1] < i && code == ix.special_code[1]);
-}
-
-// exec_exact_match (searcher.hpp:102-105) for the two bases read[j], read[j+1] at once; `two` = their packed codes.
-// Returns false when the interval died: lo/hi then hold what the upstream loop stops with (it stops after the
-// FIRST base if that one already emptied the interval, searcher.hpp:406, so that base is replayed alone).
-__device__ __forceinline__ bool step_two_bases(const DeviceIndex& ix, uint32_t two, uint64_t& lo, uint64_t& hi) {
-  two ^= 15u;                                            // complement: the query is RC(read)
-  const uint32_t code = ((two & 3u) << 2) | (two >> 2);  // x = first prepended base, y = second
-  const uint64_t b_lo = lo >> 6;
-  const bool same = ((hi - 1) >> 6) == b_lo;             // both ends in one block: one access serves both
-  const Step2 s1 = load_step2(ix, b_lo, code);
-  uint64_t nlo = s1.base + (uint64_t)__popcll(s1.mask & below((uint32_t)(lo & 63)));
-  uint64_t nhi;
-  if (same) {
-    nhi = s1.base + (uint64_t)__popcll(s1.mask & below((uint32_t)(hi - (b_lo << 6))));
-  } else {
-    const Step2 s2 = load_step2(ix, hi >> 6, code);
-    nhi = s2.base + (uint64_t)__popcll(s2.mask & below((uint32_t)(hi & 63)));
-  }
-  nlo -= rank2_correction(ix, code, lo);
-  nhi -= rank2_correction(ix, code, hi);
-  if (nlo >= nhi) {
-    const uint64_t l1 = lf1(ix, lo, code >> 2), h1 = lf1(ix, hi, code >> 2);
-    if (l1 >= h1) { lo = l1; hi = h1; } else { lo = nlo; hi = nhi; }
-    return false;
-  }
-  lo = nlo;
-  hi = nhi;
-  return true;
-}
-
-// searcher.hpp:504-539 for one lane
-__device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
-                                                   sbwt_hit* out) {
+// searcher.hpp:504-539 for one lane.  chr / npos are the sorted key arrays (global memory or the workgroup's LDS
+// copy).  The upstream test "first and last base fall into the same chromosome / the same N-free segment"
+// (upper_bound - 1 of both ends, :519-533) is: no key lies in (position, position + L - 1].
+__device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos,
+                                                   uint64_t position, uint32_t L, int strand, sbwt_hit* out) {
   bool is_rc = false;
   if (position >= ix.real_size) {
     is_rc = true;
     position = ix.real_size * 2 - position - L;
   }
   if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
-  const uint32_t c1 = upper_bound_minus1(ix.chr_start, ix.n_chr, position);
-  const uint32_t c3 = upper_bound_minus1(ix.chr_start, ix.n_chr, position + L - 1);
-  if (c1 != c3) return false;
-  const uint32_t n1 = upper_bound_minus1(ix.npos_key, ix.n_npos, position);
-  const uint32_t n3 = upper_bound_minus1(ix.npos_key, ix.n_npos, position + L - 1);
-  if (n1 != n3) return false;
-  out->pos0 = position - ix.chr_start[c1] + ix.npos_val[n1];
+  const uint64_t last = position + L - 1;
+  const uint32_t c1 = upper_bound_minus1(chr, ix.n_chr, position);
+  if (c1 + 1 < ix.n_chr && chr[c1 + 1] <= last) return false;
+  const uint32_t n1 = upper_bound_minus1(npos, ix.n_npos, position);
+  if (n1 + 1 < ix.n_npos && npos[n1 + 1] <= last) return false;
+  out->pos0 = position - chr[c1] + ix.npos_val[n1];
   out->chr_id = c1;
   out->is_rc = is_rc ? 1u : 0u;
   return true;
+}
+__device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
+                                                   sbwt_hit* out) {
+  return push_position_keys(ix, ix.chr_start, ix.npos_key, position, L, strand, out);
+}
+
+// bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
+__device__ __forceinline__ void funnel128(uint64_t q0, uint64_t q1, uint64_t q2, uint64_t q3, uint32_t o,
+                                          uint64_t& c0, uint64_t& c1) {
+  uint32_t sh = 2 * o;
+  if (sh >= 64) { q0 = q1; q1 = q2; q2 = q3; sh -= 64; }
+  c0 = sh ? ((q0 >> sh) | (q1 << (64 - sh))) : q0;
+  c1 = sh ? ((q1 >> sh) | (q2 << (64 - sh))) : q1;
 }
 
 // Phases, chosen so that the lanes of a wave wait on memory together (the walk is latency-bound: throughput is
@@ -146,154 +108,198 @@ __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64
 //   3. leftovers (repeats, reads near an LF-inconsistent row or the text start): two-base steps to the end;
 //   4. suppression test, unique-hit position filters (push_position), hit slot, result record.
 constexpr int kNarrowIters = 6;
+constexpr uint32_t kMaxLdsKeys = 2048;  // chr_start + npos_key entries kept in LDS (16 KB); larger maps stay in global memory
 
+// Persistent workgroups: each strides over the batch, so the filter tables are staged in LDS once per workgroup.
+template <bool kLds>
 __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapArgs a) {
-  const uint64_t r = global_thread();
-  if (r >= a.n_reads) return;
-  const uint32_t L = a.lens[r];
-  const uint32_t* rp = a.packed + r * (uint64_t)a.wpr;
-  uint64_t lo = 0, hi = 0, located = 0;
-  bool have_located = false;
-  uint32_t flags = 0;
-  uint32_t j = kKmer;
-  bool alive = true;  // false once the interval died (lo/hi final)
-  if (L < (uint32_t)kKmer || L > a.wpr * 16u) {
-    flags = kFlagInvalid;
-    alive = false;
-    j = L;
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+  const uint64_t* chr = ix.chr_start;
+  const uint64_t* npos = ix.npos_key;
+  if (kLds) {
+    for (uint32_t k = threadIdx.x; k < ix.n_chr + ix.n_npos; k += blockDim.x)
+      s_keys[k] = k < ix.n_chr ? ix.chr_start[k] : ix.npos_key[k - ix.n_chr];
+    __syncthreads();
+    chr = s_keys;
+    npos = s_keys + ix.n_chr;
   }
-  // bases 0..63; base j sits at bits 2j.  The upstream query is RC(read): walking it from its end is walking
-  // the read from its start with every base complemented (code ^ 3).
-  const uint4 w = *reinterpret_cast<const uint4*>(rp);
-  const uint64_t w_lo = ((uint64_t)w.y << 32) | w.x;  // bases 0..31
-  if (alive) {
-    // init_exact_match (searcher.hpp:83-96): sum_k q[L-12+k] * 4^(11-k) with q[L-12+k] = 3 - read[11-k]
-    const uint32_t kmer = (~w.x) & 0xFFFFFFu;
-    lo = ix.c_functions[kmer];
-    hi = ix.c_functions[kmer + 1];
-    alive = lo < hi;
-  }
-  // ---- phase 1 (j stays below 32: bases come from w_lo)
-#pragma unroll 1
-  for (int it = 0; it < kNarrowIters; ++it) {
-    const bool act = alive && hi - lo > 1 && j + 1 < L;
-    if (!__any(act)) break;
-    if (act) {
-      alive = step_two_bases(ix, (uint32_t)(w_lo >> (2 * j)) & 15u, lo, hi);
-      if (alive) j += 2;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x; r0 < a.n_reads; r0 += stride) {
+    const uint64_t r = r0 + threadIdx.x;
+    const bool valid = r < a.n_reads;
+    const uint32_t L = valid ? a.lens[r] : 0u;
+    const uint32_t* rp = a.packed + (valid ? r : 0) * (uint64_t)a.wpr;
+    uint64_t lo = 0, hi = 0, located = 0;
+    bool have_located = false;
+    uint32_t flags = 0;
+    uint32_t j = kKmer;
+    bool alive = valid;  // false once the interval died (lo/hi final)
+    if (valid && (L < (uint32_t)kKmer || L > a.wpr * 16u)) {
+      flags = kFlagInvalid;
+      alive = false;
     }
-  }
-  // ---- phase 2
-  if (alive && hi - lo == 1 && j < L) {
-    const uint64_t e = ix.sa_full[lo];
-    const uint64_t p = e & kPosMask, run = e >> kPosBits;
-    const uint32_t rem = L - j;
-    if (e != kNoPosition && run > (uint64_t)rem && p >= (uint64_t)rem) {
-      const uint64_t x0 = ix.n - 1 - p;            // read[j + t] continues the match iff it equals textrc[x0 + t]
-      const uint64_t row_end = ix.row_tab[p - rem];  // needed unless a base differs; fetched alongside the text
-      uint64_t d0 = read_bits64(rp, a.wpr, j) ^ text_bits64(ix.textrc, x0);
-      uint64_t d1 = 0;
-      if (rem > 32u) d1 = read_bits64(rp, a.wpr, j + 32u) ^ text_bits64(ix.textrc, x0 + 32u);
-      if (rem < 32u) d0 &= (1ull << (2 * rem)) - 1ull;
-      if (rem < 64u && rem > 32u) d1 &= (1ull << (2 * (rem - 32u))) - 1ull;
-      uint32_t t = rem;  // first differing base, rem = none
-      if (d0) t = (uint32_t)(__ffsll((unsigned long long)d0) - 1) >> 1;
-      else if (d1) t = 32u + ((uint32_t)(__ffsll((unsigned long long)d1) - 1) >> 1);
-      else {
-        for (uint32_t u = 64u; u < rem; u += 32u) {  // reads longer than 64 + j bases
-          const uint32_t nb = rem - u < 32u ? rem - u : 32u;
-          uint64_t d = read_bits64(rp, a.wpr, j + u) ^ text_bits64(ix.textrc, x0 + u);
-          if (nb < 32u) d &= (1ull << (2 * nb)) - 1ull;
-          if (d) {
-            t = u + ((uint32_t)(__ffsll((unsigned long long)d) - 1) >> 1);
-            break;
+    // bases 0..63; base j sits at bits 2j.  The upstream query is RC(read): walking it from its end is walking
+    // the read from its start with every base complemented (code ^ 3).
+    const uint4 w = *reinterpret_cast<const uint4*>(rp);
+    const uint64_t w_lo = ((uint64_t)w.y << 32) | w.x, w_hi = ((uint64_t)w.w << 32) | w.z;  // bases 0..31, 32..63
+    if (alive) {
+      bool memo = false;
+      if (ix.kmer_tab && L >= ix.kmer_order) {
+        // the first kmer_order bases at once (device_layout.h: kmer_tab)
+        const uint64_t e = ix.kmer_tab[ix.kmer_order == 16u ? ~w.x : ((~w.x) & ((1u << (2 * ix.kmer_order)) - 1u))];
+        const uint64_t width = e >> kPosBits;
+        if (width != kKmerWide) {
+          lo = e & kPosMask;
+          hi = lo + width;
+          j = ix.kmer_order;
+          memo = true;
+        }
+      }
+      if (!memo) {
+        // init_exact_match (searcher.hpp:83-96): sum_k q[L-12+k] * 4^(11-k) with q[L-12+k] = 3 - read[11-k]
+        const uint32_t kmer = (~w.x) & 0xFFFFFFu;
+        lo = ix.c_functions[kmer];
+        hi = ix.c_functions[kmer + 1];
+      }
+      alive = lo < hi;
+    }
+    // ---- phase 1 (j stays below 32: bases come from w_lo)
+#pragma unroll 1
+    for (int it = 0; it < kNarrowIters; ++it) {
+      const bool act = alive && hi - lo > 1 && j + 1 < L;
+      if (!__any(act)) break;
+      if (act) {
+        alive = step_two_bases(ix, (uint32_t)(w_lo >> (2 * j)) & 15u, lo, hi);
+        if (alive) j += 2;
+      }
+    }
+    // ---- phase 2
+    if (alive && hi - lo == 1 && j < L) {
+      const uint64_t e = ix.sa_full[lo];
+      const uint64_t p = e & kPosMask, run = e >> kPosBits;
+      const uint32_t rem = L - j;
+      if (e != kNoPosition && run > (uint64_t)rem && p >= (uint64_t)rem) {
+        const uint64_t x0 = ix.n - 1 - p;            // read[j + t] continues the match iff it equals textrc[x0 + t]
+        const uint64_t row_end = ix.row_tab[p - rem];  // needed unless a base differs; fetched alongside the text
+        uint64_t d0, d1 = 0;
+        if (L <= 64u) {
+          // the whole read is in w, and its remainder spans at most two aligned 16-byte pieces of the text
+          const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
+          const uint4 ta = t4[0], tb = t4[1];
+          uint64_t t0, t1;
+          funnel128(((uint64_t)ta.y << 32) | ta.x, ((uint64_t)ta.w << 32) | ta.z, ((uint64_t)tb.y << 32) | tb.x,
+                    ((uint64_t)tb.w << 32) | tb.z, (uint32_t)(x0 & 63), t0, t1);
+          const uint32_t sh = 2 * j;  // 24 <= sh < 64 here (j < 32 after phase 1)
+          d0 = ((w_lo >> sh) | (w_hi << (64 - sh))) ^ t0;
+          d1 = (w_hi >> sh) ^ t1;
+        } else {
+          d0 = read_bits64(rp, a.wpr, j) ^ text_bits64(ix.textrc, x0);
+          if (rem > 32u) d1 = read_bits64(rp, a.wpr, j + 32u) ^ text_bits64(ix.textrc, x0 + 32u);
+        }
+        if (rem < 32u) d0 &= (1ull << (2 * rem)) - 1ull;
+        if (rem <= 32u) d1 = 0;
+        else if (rem < 64u) d1 &= (1ull << (2 * (rem - 32u))) - 1ull;
+        uint32_t t = rem;  // first differing base, rem = none
+        if (d0) t = (uint32_t)(__ffsll((unsigned long long)d0) - 1) >> 1;
+        else if (d1) t = 32u + ((uint32_t)(__ffsll((unsigned long long)d1) - 1) >> 1);
+        else {
+          for (uint32_t u = 64u; u < rem; u += 32u) {  // reads longer than 64 + j bases
+            const uint32_t nb = rem - u < 32u ? rem - u : 32u;
+            uint64_t d = read_bits64(rp, a.wpr, j + u) ^ text_bits64(ix.textrc, x0 + u);
+            if (nb < 32u) d &= (1ull << (2 * nb)) - 1ull;
+            if (d) {
+              t = u + ((uint32_t)(__ffsll((unsigned long long)d) - 1) >> 1);
+              break;
+            }
+          }
+        }
+        if (t == rem) {
+          lo = row_end;
+          hi = lo + 1;
+          located = p - rem;
+          have_located = true;
+        } else {
+          // the chain dies at base j + t: exec_exact_match on the row reached after t matching bases
+          const uint64_t it = t ? ix.row_tab[p - t] : lo;
+          const uint32_t c = ((rp[(j + t) >> 4] >> (2 * ((j + t) & 15u))) & 3u) ^ 3u;
+          lo = lf1(ix, it, c);
+          hi = lf1(ix, it + 1, c);
+          alive = false;
+        }
+        j = L;
+      }
+    }
+    // ---- phase 3
+    while (alive && j < L) {
+      if (j + 1 == L) {  // last base alone
+        const uint32_t c = ((rp[j >> 4] >> (2 * (j & 15u))) & 3u) ^ 3u;
+        const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
+        lo = l1;
+        hi = h1;
+        alive = lo < hi;
+        j += 1;
+      } else {
+        alive = step_two_bases(ix, (rp[j >> 4] >> (2 * (j & 15u))) & 15u, lo, hi);  // j is even: one word
+        if (alive) j += 2;
+      }
+    }
+
+    // ---- phase 4
+    int32_t nh = 0;
+    uint64_t first_hit = 0;
+    bool unique_ok = false;
+    sbwt_hit h;
+    const uint64_t m = hi > lo ? hi - lo : 0;
+    if (m > a.limit) {
+      flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
+    } else if (m == 1) {
+      // the text comparison already knows the position; otherwise one gather of the memoised locate
+      const uint64_t e0 = have_located ? located : ix.sa_full[lo];
+      if (e0 != kNoPosition) unique_ok = push_position_keys(ix, chr, npos, e0 & kPosMask, L, a.strand, &h);
+    }
+    {
+      // one slot in hits[] per surviving unique hit, handed out with one atomic per wave
+      const uint64_t wmask = __ballot(unique_ok);
+      if (wmask) {
+        const uint32_t lane = threadIdx.x & 63;
+        const int leader = __ffsll((unsigned long long)wmask) - 1;
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(&a.ctr->hit_count, (unsigned long long)__popcll(wmask));
+        base = ((unsigned long long)__shfl((int)(base >> 32), leader) << 32) |
+               (unsigned int)__shfl((int)(base & 0xffffffffu), leader);
+        if (unique_ok) {
+          const uint64_t slot = base + (uint64_t)__popcll(wmask & ((1ull << lane) - 1));
+          if (slot < a.hits_cap) {
+            a.hits[slot] = h;
+            first_hit = slot;
+            nh = 1;
+          } else {
+            atomicOr(&a.ctr->overflow, 1u);
           }
         }
       }
-      if (t == rem) {
-        lo = row_end;
-        hi = lo + 1;
-        located = p - rem;
-        have_located = true;
+    }
+    if (m > 1 && m <= a.limit) {
+      // multi-hit read: reserve m slots and hand the read to k_multi
+      const uint64_t slot = atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
+      if (slot + m <= a.hits_cap) {
+        first_hit = slot;
+        const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
+        a.multi_queue[q] = (uint32_t)r;
       } else {
-        // the chain dies at base j + t: exec_exact_match on the row reached after t matching bases
-        const uint64_t it = t ? ix.row_tab[p - t] : lo;
-        const uint32_t c = ((rp[(j + t) >> 4] >> (2 * ((j + t) & 15u))) & 3u) ^ 3u;
-        lo = lf1(ix, it, c);
-        hi = lf1(ix, it + 1, c);
-        alive = false;
-      }
-      j = L;
-    }
-  }
-  // ---- phase 3
-  while (alive && j < L) {
-    if (j + 1 == L) {  // last base alone
-      const uint32_t c = ((rp[j >> 4] >> (2 * (j & 15u))) & 3u) ^ 3u;
-      const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
-      lo = l1;
-      hi = h1;
-      alive = lo < hi;
-      j += 1;
-    } else {
-      alive = step_two_bases(ix, (rp[j >> 4] >> (2 * (j & 15u))) & 15u, lo, hi);  // j is even: one word
-      if (alive) j += 2;
-    }
-  }
-
-  // ---- phase 4
-  int32_t nh = 0;
-  uint64_t first_hit = 0;
-  bool unique_ok = false;
-  sbwt_hit h;
-  const uint64_t m = hi > lo ? hi - lo : 0;
-  if (m > a.limit) {
-    flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
-  } else if (m == 1) {
-    // the text comparison already knows the position; otherwise one gather of the memoised locate
-    const uint64_t e0 = have_located ? located : ix.sa_full[lo];
-    if (e0 != kNoPosition) unique_ok = push_position_lane(ix, e0 & kPosMask, L, a.strand, &h);
-  }
-  {
-    // one slot in hits[] per surviving unique hit, handed out with one atomic per wave
-    const uint64_t wmask = __ballot(unique_ok);
-    if (wmask) {
-      const uint32_t lane = threadIdx.x & 63;
-      const int leader = __ffsll((unsigned long long)wmask) - 1;
-      unsigned long long base = 0;
-      if ((int)lane == leader) base = atomicAdd(&a.ctr->hit_count, (unsigned long long)__popcll(wmask));
-      base = ((unsigned long long)__shfl((int)(base >> 32), leader) << 32) |
-             (unsigned int)__shfl((int)(base & 0xffffffffu), leader);
-      if (unique_ok) {
-        const uint64_t slot = base + (uint64_t)__popcll(wmask & ((1ull << lane) - 1));
-        if (slot < a.hits_cap) {
-          a.hits[slot] = h;
-          first_hit = slot;
-          nh = 1;
-        } else {
-          atomicOr(&a.ctr->overflow, 1u);
-        }
+        atomicOr(&a.ctr->overflow, 1u);
       }
     }
-  }
-  if (m > 1 && m <= a.limit) {
-    // multi-hit read: reserve m slots and hand the read to k_multi
-    const uint64_t slot = atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
-    if (slot + m <= a.hits_cap) {
-      first_hit = slot;
-      const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
-      a.multi_queue[q] = (uint32_t)r;
-    } else {
-      atomicOr(&a.ctr->overflow, 1u);
+    if (valid) {
+      sbwt_read_result res;
+      res.sa_lo = lo;
+      res.sa_hi = hi;
+      res.first_hit = first_hit;
+      res.nh = nh;
+      res.flags = flags;
+      a.results[r] = res;
     }
   }
-  sbwt_read_result res;
-  res.sa_lo = lo;
-  res.sa_hi = hi;
-  res.first_hit = first_hit;
-  res.nh = nh;
-  res.flags = flags;
-  a.results[r] = res;
 }
 
 // ---- multi-hit locate: the upstream DFS, one lane per queued read -----------------------------
@@ -394,6 +400,7 @@ struct sbwt_ctx {
   uint32_t* d_queue = nullptr;
   Frame* d_stacks = nullptr;
   uint32_t multi_lanes = 0;
+  uint32_t grid_lds = 0, grid_glb = 0;  // resident workgroups of k_search<true> / k_search<false>
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
   // staging for the host-buffer entry point
@@ -422,6 +429,20 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (c->multi_lanes > max_reads) c->multi_lanes = (uint32_t)((max_reads + 255) / 256 * 256);
   if (e == hipSuccess) e = hipMalloc(&c->d_stacks, (uint64_t)c->multi_lanes * ix->d.interval * sizeof(Frame));
   for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+  if (e == hipSuccess) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, ix->device);
+    int per_cu_lds = 0, per_cu_glb = 0;
+    const size_t lds_bytes = (size_t)(ix->d.n_chr + ix->d.n_npos) * sizeof(uint64_t);
+    if (e == hipSuccess)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lds, k_search<true>, 256,
+                                                       lds_bytes <= kMaxLdsKeys * sizeof(uint64_t) ? lds_bytes : 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_glb, k_search<false>, 256, 0);
+    if (e == hipSuccess) {
+      c->grid_lds = (uint32_t)(prop.multiProcessorCount * (per_cu_lds > 0 ? per_cu_lds : 1));
+      c->grid_glb = (uint32_t)(prop.multiProcessorCount * (per_cu_glb > 0 ? per_cu_glb : 1));
+    }
+  }
   if (e != hipSuccess) {
     sbwt_ctx_free(c);
     return hip_fail(e, "sbwt_ctx_create", __FILE__, __LINE__);
@@ -481,8 +502,17 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   a.multi_queue = c->d_queue;
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
-  k_search<<<grid_items(n_reads, 256), 256, 0, c->stream>>>(c->ix->d, a);
-  SBWT_LAUNCHED();
+  {
+    // persistent grid: as many workgroups as the device keeps resident, never more than the batch needs
+    const DeviceIndex& d = c->ix->d;
+    const uint32_t n_keys = d.n_chr + d.n_npos;
+    const bool lds = n_keys <= kMaxLdsKeys;
+    const uint64_t need = (n_reads + 255) / 256;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_lds : c->grid_glb);
+    if (lds) k_search<true><<<grid, 256, n_keys * sizeof(uint64_t), c->stream>>>(d, a);
+    else k_search<false><<<grid, 256, 0, c->stream>>>(d, a);
+    SBWT_LAUNCHED();
+  }
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
   k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(c->ix->d, a, c->d_stacks, c->multi_lanes);
   SBWT_HIP(hipEventRecord(c->ev[2], c->stream));

@@ -38,6 +38,59 @@ __device__ __forceinline__ uint64_t lf1(const DeviceIndex& ix, uint64_t i, uint3
   return r;
 }
 
+// One Block2 as seen by one read: positions whose code matches, and the count before the block
+// (K2[code] + superblock absolute + block relative).  rank2(code, i) = base + popcount(mask & below(i & 63)).
+struct Step2 {
+  uint64_t mask;
+  uint64_t base;
+};
+__device__ __forceinline__ Step2 load_step2(const DeviceIndex& ix, uint64_t blk, uint32_t code) {
+  const Block2* b = ix.blocks2 + blk;
+  const uint4 p01 = *reinterpret_cast<const uint4*>(&b->plane[0]);  // bits of y
+  const uint4 p23 = *reinterpret_cast<const uint4*>(&b->plane[2]);  // bits of x
+  const uint32_t cn = b->cnt[code];
+  const uint64_t sb = ix.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code];
+  const uint64_t q0 = ((uint64_t)p01.y << 32) | p01.x, q1 = ((uint64_t)p01.w << 32) | p01.z;
+  const uint64_t q2 = ((uint64_t)p23.y << 32) | p23.x, q3 = ((uint64_t)p23.w << 32) | p23.z;
+  Step2 s;
+  s.mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
+  s.base = sb + cn;
+  return s;
+}
+__device__ __forceinline__ uint64_t rank2_correction(const DeviceIndex& ix, uint32_t code, uint64_t i) {
+  return (uint64_t)(ix.special_pos[0] < i && code == ix.special_code[0]) +
+         (uint64_t)(ix.special_pos[1] < i && code == ix.special_code[1]);
+}
+
+// exec_exact_match (searcher.hpp:102-105) for the two bases read[j], read[j+1] at once; `two` = their packed codes.
+// Returns false when the interval died: lo/hi then hold what the upstream loop stops with (it stops after the
+// FIRST base if that one already emptied the interval, searcher.hpp:406, so that base is replayed alone).
+__device__ __forceinline__ bool step_two_bases(const DeviceIndex& ix, uint32_t two, uint64_t& lo, uint64_t& hi) {
+  two ^= 15u;                                            // complement: the query is RC(read)
+  const uint32_t code = ((two & 3u) << 2) | (two >> 2);  // x = first prepended base, y = second
+  const uint64_t b_lo = lo >> 6;
+  const bool same = ((hi - 1) >> 6) == b_lo;             // both ends in one block: one access serves both
+  const Step2 s1 = load_step2(ix, b_lo, code);
+  uint64_t nlo = s1.base + (uint64_t)__popcll(s1.mask & below((uint32_t)(lo & 63)));
+  uint64_t nhi;
+  if (same) {
+    nhi = s1.base + (uint64_t)__popcll(s1.mask & below((uint32_t)(hi - (b_lo << 6))));
+  } else {
+    const Step2 s2 = load_step2(ix, hi >> 6, code);
+    nhi = s2.base + (uint64_t)__popcll(s2.mask & below((uint32_t)(hi & 63)));
+  }
+  nlo -= rank2_correction(ix, code, lo);
+  nhi -= rank2_correction(ix, code, hi);
+  if (nlo >= nhi) {
+    const uint64_t l1 = lf1(ix, lo, code >> 2), h1 = lf1(ix, hi, code >> 2);
+    if (l1 >= h1) { lo = l1; hi = h1; } else { lo = nlo; hi = nhi; }
+    return false;
+  }
+  lo = nlo;
+  hi = nhi;
+  return true;
+}
+
 // std::map::upper_bound(x) followed by advance(-1) (searcher.hpp:519-533) over a sorted key array
 // whose first key is 0
 __device__ __forceinline__ uint32_t upper_bound_minus1(const uint64_t* __restrict__ keys, uint32_t n, uint64_t x) {

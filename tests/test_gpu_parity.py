@@ -43,11 +43,15 @@ def sb():
     return sbwt_amd
 
 
-@pytest.fixture(scope="module")
-def loaded(sb, oracle, golden_indexes):
+@pytest.fixture(scope="module", params=["12", "14", "16"])
+def loaded(request, sb, oracle, golden_indexes):
+    """every test runs with no memoised search prefix (12) and with the 14- and 16-base tables the loader would
+    pick for dm6- and GRCh38-sized indexes (forced here: the golden genomes are tiny)"""
+    os.environ["SBWT_KMER_ORDER"] = request.param
     out = {}
     for g, prefix in golden_indexes.items():
         out[g] = (sb.Index.load(prefix), oracle.OracleIndex.load(prefix))
+    os.environ.pop("SBWT_KMER_ORDER")
     yield out
     for ix, oix in out.values():
         ix.close()
