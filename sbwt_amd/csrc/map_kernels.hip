@@ -12,6 +12,7 @@
 //   k_multi  : the upstream depth-first locate, statement for statement, for the queued reads.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -20,11 +21,12 @@
 #include "../../include/sbwt_amd.h"
 #include "index_impl.hpp"
 #include "rank_device.h"
+#include "search_machine.h"
 
 namespace sbwt {
 
 struct Counters {
-  unsigned long long hit_count;    // slots handed out in hits[]
+  unsigned long long hit_count;    // slots handed out in hits[] behind the first n_reads (multi-hit reads)
   unsigned long long multi_count;  // reads queued for k_multi
   unsigned int overflow;           // hits[] too small
   unsigned int pad;
@@ -112,7 +114,7 @@ constexpr uint32_t kMaxLdsKeys = 2048;  // chr_start + npos_key entries kept in 
 
 // Persistent workgroups: each strides over the batch, so the filter tables are staged in LDS once per workgroup.
 template <bool kLds>
-__global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapArgs a) {
+__global__ __launch_bounds__(256) void k_search_phased(const DeviceIndex ix, const MapArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
   const uint64_t* chr = ix.chr_start;
   const uint64_t* npos = ix.npos_key;
@@ -257,31 +259,14 @@ __global__ __launch_bounds__(256) void k_search(const DeviceIndex ix, const MapA
       const uint64_t e0 = have_located ? located : ix.sa_full[lo];
       if (e0 != kNoPosition) unique_ok = push_position_keys(ix, chr, npos, e0 & kPosMask, L, a.strand, &h);
     }
-    {
-      // one slot in hits[] per surviving unique hit, handed out with one atomic per wave
-      const uint64_t wmask = __ballot(unique_ok);
-      if (wmask) {
-        const uint32_t lane = threadIdx.x & 63;
-        const int leader = __ffsll((unsigned long long)wmask) - 1;
-        unsigned long long base = 0;
-        if ((int)lane == leader) base = atomicAdd(&a.ctr->hit_count, (unsigned long long)__popcll(wmask));
-        base = ((unsigned long long)__shfl((int)(base >> 32), leader) << 32) |
-               (unsigned int)__shfl((int)(base & 0xffffffffu), leader);
-        if (unique_ok) {
-          const uint64_t slot = base + (uint64_t)__popcll(wmask & ((1ull << lane) - 1));
-          if (slot < a.hits_cap) {
-            a.hits[slot] = h;
-            first_hit = slot;
-            nh = 1;
-          } else {
-            atomicOr(&a.ctr->overflow, 1u);
-          }
-        }
-      }
+    if (unique_ok) {
+      a.hits[r] = h;  // unique hits live at the read's own index
+      first_hit = r;
+      nh = 1;
     }
     if (m > 1 && m <= a.limit) {
       // multi-hit read: reserve m slots and hand the read to k_multi
-      const uint64_t slot = atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
+      const uint64_t slot = a.n_reads + atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
       if (slot + m <= a.hits_cap) {
         first_hit = slot;
         const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
@@ -400,7 +385,10 @@ struct sbwt_ctx {
   uint32_t* d_queue = nullptr;
   Frame* d_stacks = nullptr;
   uint32_t multi_lanes = 0;
-  uint32_t grid_lds = 0, grid_glb = 0;  // resident workgroups of k_search<true> / k_search<false>
+  uint32_t grid_lds = 0, grid_glb = 0;  // resident workgroups of k_search_phased<true> / k_search_phased<false>
+  uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // same for k_search_sm
+  size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
+  bool use_phased = false;                    // SBWT_KERNEL=phased: the phase-by-phase kernel (kept for A/B timing)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
   // staging for the host-buffer entry point
@@ -435,13 +423,25 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     int per_cu_lds = 0, per_cu_glb = 0;
     const size_t lds_bytes = (size_t)(ix->d.n_chr + ix->d.n_npos) * sizeof(uint64_t);
     if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lds, k_search<true>, 256,
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lds, k_search_phased<true>, 256,
                                                        lds_bytes <= kMaxLdsKeys * sizeof(uint64_t) ? lds_bytes : 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_glb, k_search<false>, 256, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_glb, k_search_phased<false>, 256, 0);
     if (e == hipSuccess) {
       c->grid_lds = (uint32_t)(prop.multiProcessorCount * (per_cu_lds > 0 ? per_cu_lds : 1));
       c->grid_glb = (uint32_t)(prop.multiProcessorCount * (per_cu_glb > 0 ? per_cu_glb : 1));
     }
+    const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
+    if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys && n_super <= kSmMaxSuper)
+      c->sm_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super) * sizeof(uint64_t);
+    int sm_lds = 0, sm_glb = 0;
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, 0);
+    if (e == hipSuccess) {
+      c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
+      c->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
+    }
+    const char* kv = getenv("SBWT_KERNEL");
+    c->use_phased = kv && !strcmp(kv, "phased");
   }
   if (e != hipSuccess) {
     sbwt_ctx_free(c);
@@ -487,6 +487,15 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   }
   if (n_hits_host) *n_hits_host = 0;
   if (n_reads == 0) return SBWT_OK;
+  if (hits_cap < n_reads) {
+    // unique hits are written at their read's index: hits[] holds one slot per read, multi-hit lists behind them
+    char msg[160];
+    snprintf(msg, sizeof msg, "hits buffer too small: at least one slot per read (%llu) is needed, %llu provided",
+             (unsigned long long)n_reads, (unsigned long long)hits_cap);
+    set_error(msg);
+    if (n_hits_host) *n_hits_host = n_reads;
+    return SBWT_ERR_CAPACITY;
+  }
   SBWT_HIP(hipSetDevice(c->ix->device));
   MapArgs a;
   a.packed = d_packed;
@@ -502,15 +511,36 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   a.multi_queue = c->d_queue;
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
-  {
+  const DeviceIndex& d = c->ix->d;
+  if (c->use_phased) {
     // persistent grid: as many workgroups as the device keeps resident, never more than the batch needs
-    const DeviceIndex& d = c->ix->d;
     const uint32_t n_keys = d.n_chr + d.n_npos;
     const bool lds = n_keys <= kMaxLdsKeys;
     const uint64_t need = (n_reads + 255) / 256;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_lds : c->grid_glb);
-    if (lds) k_search<true><<<grid, 256, n_keys * sizeof(uint64_t), c->stream>>>(d, a);
-    else k_search<false><<<grid, 256, 0, c->stream>>>(d, a);
+    if (lds) k_search_phased<true><<<grid, 256, n_keys * sizeof(uint64_t), c->stream>>>(d, a);
+    else k_search_phased<false><<<grid, 256, 0, c->stream>>>(d, a);
+    SBWT_LAUNCHED();
+  } else {
+    SmArgs sa;
+    sa.packed = d_packed;
+    sa.lens = d_lens;
+    sa.n_reads = n_reads;
+    sa.wpr = words_per_read;
+    sa.strand = strand;
+    sa.limit = a.limit;
+    sa.results = d_results;
+    sa.hits = d_hits;
+    sa.hits_cap = hits_cap;
+    sa.multi_slots = &c->d_ctr->hit_count;
+    sa.multi_count = &c->d_ctr->multi_count;
+    sa.overflow = &c->d_ctr->overflow;
+    sa.multi_queue = c->d_queue;
+    const bool lds = c->sm_lds_bytes != 0;
+    const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);
+    if (lds) k_search_sm<true><<<grid, 256, c->sm_lds_bytes, c->stream>>>(d, sa);
+    else k_search_sm<false><<<grid, 256, 0, c->stream>>>(d, sa);
     SBWT_LAUNCHED();
   }
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
@@ -522,15 +552,16 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[2]);
   hipEventElapsedTime(&c->last_ms[1], c->ev[0], c->ev[1]);
   hipEventElapsedTime(&c->last_ms[2], c->ev[1], c->ev[2]);
+  const uint64_t used = n_reads + c->h_ctr->hit_count;  // one slot per read + the multi-hit lists
   if (c->h_ctr->overflow) {
     char msg[160];
-    snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided",
-             (unsigned long long)c->h_ctr->hit_count, (unsigned long long)hits_cap);
+    snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided", (unsigned long long)used,
+             (unsigned long long)hits_cap);
     set_error(msg);
-    if (n_hits_host) *n_hits_host = c->h_ctr->hit_count;  // what a retry needs
+    if (n_hits_host) *n_hits_host = used;  // what a retry needs
     return SBWT_ERR_CAPACITY;
   }
-  if (n_hits_host) *n_hits_host = c->h_ctr->hit_count;
+  if (n_hits_host) *n_hits_host = used;
   return SBWT_OK;
 }
 

@@ -1,0 +1,452 @@
+// search_machine.h -- k_search_sm: the per-read search as a lane-level state machine.
+//
+// The walk is latency-bound: a read is a chain of 4..8 dependent random HBM accesses (search prefix table, zero
+// or more two-base steps, memoised locate, text comparison + final row), and reads differ in chain length.  A
+// kernel that walks "one read per lane, phase by phase" leaves lanes idle whenever their neighbours need a step
+// more.  Here every lane runs its own chain: each loop iteration a lane issues the loads of its CURRENT state
+// through a fixed set of load slots (two 16-byte, one 16-byte read piece, two 8-byte, one 4-byte), the wave waits
+// ONCE, every lane consumes its slots and moves to its next state, and a lane whose read is finished takes the
+// next read of the wave's range.  All memory waits of all reads of the wave overlap, whatever their state.
+//
+// The arithmetic of every state is the upstream one (searcher.hpp:386-539), stated next to each state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sbwt_amd.h"
+#include "rank_device.h"
+
+namespace sbwt {
+
+enum SmState : uint32_t {
+  S_DONE = 0,   // wants a new read
+  S_IDLE,       // the wave's range is exhausted
+  S_FETCH,      // read record: first 64 bases + length
+  S_KMER,       // search prefix: kmer_tab entry, or the c_functions pair (init_exact_match, searcher.hpp:83-96)
+  S_STEP_LO,    // two-base step, block of lo (and of hi when it is the same block)
+  S_STEP_HI,    // two-base step, block of hi
+  S_LF1,        // one base on both ends (last odd base / replay of a dying step / the base a text comparison died on)
+  S_SA,         // sa_full[lo]: can the rest of the read be compared with the text?
+  S_CMP,        // text comparison of up to 64 bases (+ the final row once the last chunk is in flight)
+  S_MISROW,     // row of the text position a comparison died at
+  S_REFETCH,    // next 64-base piece of the read (stepping across a piece boundary; reads longer than 64 only)
+  S_LOCATE,     // sa_full[lo] of a finished size-1 interval
+};
+enum SmMode : uint32_t { M_LAST = 0, M_REPLAY = 1, M_DEAD = 2 };
+
+struct SmTables {  // LDS copies (or the global originals when they do not fit)
+  const uint64_t* chr;
+  const uint64_t* npos_key;
+  const uint64_t* npos_val;
+  const uint64_t* sb_abs;
+};
+
+// push_position (searcher.hpp:504-539); tables in LDS when kLds
+__device__ __forceinline__ bool sm_push_position(const DeviceIndex& ix, const SmTables& T, uint64_t position, uint32_t L,
+                                                 int strand, sbwt_hit* out) {
+  bool is_rc = false;
+  if (position >= ix.real_size) {
+    is_rc = true;
+    position = ix.real_size * 2 - position - L;
+  }
+  if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
+  const uint64_t last = position + L - 1;
+  const uint32_t c1 = upper_bound_minus1(T.chr, ix.n_chr, position);
+  if (c1 + 1 < ix.n_chr && T.chr[c1 + 1] <= last) return false;
+  const uint32_t n1 = upper_bound_minus1(T.npos_key, ix.n_npos, position);
+  if (n1 + 1 < ix.n_npos && T.npos_key[n1 + 1] <= last) return false;
+  out->pos0 = position - T.chr[c1] + T.npos_val[n1];
+  out->chr_id = c1;
+  out->is_rc = is_rc ? 1u : 0u;
+  return true;
+}
+
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
+__device__ __forceinline__ void sm_funnel128(uint64_t q0, uint64_t q1, uint64_t q2, uint64_t q3, uint32_t o, uint64_t& c0,
+                                             uint64_t& c1) {
+  uint32_t sh = 2 * o;
+  if (sh >= 64) { q0 = q1; q1 = q2; q2 = q3; sh -= 64; }
+  c0 = sh ? ((q0 >> sh) | (q1 << (64 - sh))) : q0;
+  c1 = sh ? ((q1 >> sh) | (q2 << (64 - sh))) : q1;
+}
+
+struct SmArgs {
+  const uint32_t* packed;
+  const uint32_t* lens;
+  uint64_t n_reads;
+  uint32_t wpr;
+  int strand;
+  uint64_t limit;
+  sbwt_read_result* results;
+  sbwt_hit* hits;
+  uint64_t hits_cap;
+  unsigned long long* multi_slots;  // slots handed out after the first n_reads (multi-hit reads)
+  unsigned long long* multi_count;
+  unsigned int* overflow;
+  uint32_t* multi_queue;
+};
+
+constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
+constexpr uint32_t kSmMaxSuper = 16;    // superblocks of sb_abs staged in LDS (2^35 suffixes)
+constexpr uint32_t kFlagInvalidSm = 0x80000000u;
+
+template <bool kLds>
+__global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_mem[];
+  SmTables T{ix.chr_start, ix.npos_key, ix.npos_val, ix.sb_abs};
+  const uint32_t n_super = (uint32_t)(((ix.n_blocks - 1) >> (kSuperShift - 6)) + 1);
+  if (kLds) {
+    uint64_t* s_chr = s_mem;
+    uint64_t* s_nk = s_chr + ix.n_chr;
+    uint64_t* s_nv = s_nk + ix.n_npos;
+    uint64_t* s_sb = s_nv + ix.n_npos;
+    for (uint32_t k = threadIdx.x; k < ix.n_chr; k += blockDim.x) s_chr[k] = ix.chr_start[k];
+    for (uint32_t k = threadIdx.x; k < ix.n_npos; k += blockDim.x) { s_nk[k] = ix.npos_key[k]; s_nv[k] = ix.npos_val[k]; }
+    for (uint32_t k = threadIdx.x; k < n_super * 16; k += blockDim.x) s_sb[k] = ix.sb_abs[k];
+    __syncthreads();
+    T.chr = s_chr; T.npos_key = s_nk; T.npos_val = s_nv; T.sb_abs = s_sb;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  // the wave's contiguous range of reads
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  uint64_t chunk = (a.n_reads + n_waves - 1) / n_waves;
+  chunk = (chunk + 63) & ~63ull;
+  uint64_t next = wave * chunk;
+  const uint64_t range_end = next + chunk < a.n_reads ? next + chunk : a.n_reads;
+
+  // lane state
+  uint32_t st = S_DONE, L = 0, j = 0, aux = 0;  // aux: code (steps) / base c (LF1) | mode << 8 | tried << 16 | located << 17
+  uint64_t r = 0, lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0;
+  uint32_t flags = 0;
+
+  for (;;) {
+    // ---- refill: finished lanes take the next reads of the range, in lane order
+    {
+      const bool want = st == S_DONE;
+      const uint64_t wm = __ballot(want);
+      if (wm) {
+        if (want) {
+          const uint64_t cand = next + (uint64_t)__popcll(wm & lane_lt);
+          if (cand < range_end) {
+            r = cand;
+            st = S_FETCH;
+            flags = 0;
+            aux = 0;
+          } else {
+            st = S_IDLE;
+          }
+        }
+        next += (uint64_t)__popcll(wm);
+      }
+      if (!__any(st != S_IDLE)) break;
+    }
+    const uint32_t* rp = a.packed + r * (uint64_t)a.wpr;
+
+    // ---- issue: every lane points the slots it needs at its own addresses
+    // (a slot a lane does not need points at the start of the batch: one cached line for the whole wave; the
+    // loads are unconditional so that all six are in flight before the single wait)
+    const uint4* const idle16 = reinterpret_cast<const uint4*>(a.packed);
+    const uint64_t* const idle8 = reinterpret_cast<const uint64_t*>(a.packed);
+    const uint4* pa = idle16;    // 16 B
+    const uint4* pb = idle16;    // 16 B
+    const uint4* pr = idle16;    // 16 B (read piece)
+    const uint64_t* pc = idle8;  // 8 B
+    const uint64_t* pe = idle8;  // 8 B
+    const uint32_t* pd = a.packed;  // 4 B
+    bool pair = false;           // S_KMER through the c_functions pair
+    switch (st) {
+      case S_FETCH:
+        pr = reinterpret_cast<const uint4*>(rp);
+        pd = a.lens + r;
+        break;
+      case S_KMER: {
+        const uint32_t cw = ~(uint32_t)w_lo;  // complemented codes of bases 0..15
+        if (ix.kmer_tab && L >= ix.kmer_order) {
+          pc = ix.kmer_tab + (ix.kmer_order == 16u ? cw : (cw & ((1u << (2 * ix.kmer_order)) - 1u)));
+        } else {
+          pc = ix.c_functions + (cw & 0xFFFFFFu);
+          pe = pc + 1;
+          pair = true;
+        }
+        break;
+      }
+      case S_STEP_LO:
+      case S_STEP_HI: {
+        const Block2* b = ix.blocks2 + ((st == S_STEP_LO ? lo : hi) >> 6);
+        pa = reinterpret_cast<const uint4*>(&b->plane[0]);
+        pb = reinterpret_cast<const uint4*>(&b->plane[2]);
+        pd = &b->cnt[aux & 15u];
+        break;
+      }
+      case S_LF1: {
+        const Block1* bl = ix.blocks1 + (lo >> 6);
+        const Block1* bh = ix.blocks1 + (hi >> 6);
+        pa = reinterpret_cast<const uint4*>(&bl->plane_lo);
+        pc = &bl->cnt[aux & 3u];
+        pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
+        pe = &bh->cnt[aux & 3u];
+        break;
+      }
+      case S_SA:
+      case S_LOCATE:
+        pc = ix.sa_full + lo;
+        break;
+      case S_CMP: {
+        const uint64_t x0 = ix.n - 1 - p;  // read[j + t] continues the match iff it equals textrc[x0 + t]
+        const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
+        pa = t4;
+        pb = t4 + 1;
+        const uint32_t piece_end = (j | 63u) + 1u;
+        if (piece_end >= L) pc = ix.row_tab + (p - (uint64_t)(L - j));   // last chunk: the final row
+        else pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
+        break;
+      }
+      case S_MISROW:
+        pc = ix.row_tab + p;
+        break;
+      case S_REFETCH:
+        pr = reinterpret_cast<const uint4*>(rp) + (j >> 6);
+        break;
+      default:
+        break;
+    }
+    // The wave barriers are no instructions; being convergent they keep the compiler from duplicating the loads
+    // into the per-state branches on either side, which would put a memory wait inside every branch.
+    __builtin_amdgcn_wave_barrier();
+    const uint4 va = *pa, vb = *pb, vr = *pr;
+    const uint64_t vc = *pc, ve = *pe;
+    const uint32_t vd = *pd;
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- consume
+    bool finish = false;  // the search part of the read is over: lo/hi final
+    switch (st) {
+      case S_FETCH: {
+        L = vd;
+        w_lo = u64_of(vr.x, vr.y);
+        w_hi = u64_of(vr.z, vr.w);
+        j = kKmer;
+        if (L < (uint32_t)kKmer || L > a.wpr * 16u) {
+          flags = kFlagInvalidSm;
+          lo = hi = 0;
+          finish = true;
+        } else {
+          st = S_KMER;
+        }
+        break;
+      }
+      case S_KMER: {
+        if (pair) {  // init_exact_match, searcher.hpp:83-96
+          lo = vc;
+          hi = ve;
+        } else {
+          const uint64_t width = vc >> kPosBits;
+          if (width == kKmerWide) {  // not memoised (interval wider than an entry holds): the 12-mer pair, read here
+            const uint32_t kmer = (~(uint32_t)w_lo) & 0xFFFFFFu;
+            lo = ix.c_functions[kmer];
+            hi = ix.c_functions[kmer + 1];
+          } else {
+            lo = vc & kPosMask;
+            hi = lo + width;
+            j = ix.kmer_order;
+          }
+        }
+        goto after_interval_update;
+      }
+      case S_STEP_LO: {
+        // exec_exact_match (searcher.hpp:102-105) for two bases; aux & 15 = code
+        const uint32_t code = aux & 15u;
+        const uint64_t blk = lo >> 6;
+        const uint64_t q0 = u64_of(va.x, va.y), q1 = u64_of(va.z, va.w), q2 = u64_of(vb.x, vb.y), q3 = u64_of(vb.z, vb.w);
+        const uint64_t mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
+        const uint64_t base = T.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code] + vd;
+        t_lo = base + (uint64_t)__popcll(mask & below((uint32_t)(lo & 63))) - rank2_correction(ix, code, lo);
+        if (((hi - 1) >> 6) == blk) {
+          t_hi = base + (uint64_t)__popcll(mask & below((uint32_t)(hi - (blk << 6)))) - rank2_correction(ix, code, hi);
+          goto after_step;
+        }
+        st = S_STEP_HI;
+        break;
+      }
+      case S_STEP_HI: {
+        const uint32_t code = aux & 15u;
+        const uint64_t blk = hi >> 6;
+        const uint64_t q0 = u64_of(va.x, va.y), q1 = u64_of(va.z, va.w), q2 = u64_of(vb.x, vb.y), q3 = u64_of(vb.z, vb.w);
+        const uint64_t mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
+        const uint64_t base = T.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code] + vd;
+        t_hi = base + (uint64_t)__popcll(mask & below((uint32_t)(hi & 63))) - rank2_correction(ix, code, hi);
+        goto after_step;
+      }
+      case S_LF1: {
+        // get_occ_using_jbwt + c_function for base c on both ends
+        const uint32_t c = aux & 3u;
+        const uint32_t mode = (aux >> 8) & 3u;
+        uint64_t l1 = vc + (uint64_t)__popcll(match1(u64_of(va.x, va.y), u64_of(va.z, va.w), c) & below((uint32_t)(lo & 63)));
+        uint64_t h1 = ve + (uint64_t)__popcll(match1(u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), c) & below((uint32_t)(hi & 63)));
+        if (c == 0 && lo > ix.first_location) l1 -= 1;
+        if (c == 0 && hi > ix.first_location) h1 -= 1;
+        if (mode == M_REPLAY) {
+          // the interval died inside a two-base step: upstream stops after the FIRST base if that one already
+          // emptied it (loop condition, searcher.hpp:406), otherwise with the two-base result
+          if (l1 >= h1) { lo = l1; hi = h1; } else { lo = t_lo; hi = t_hi; }
+        } else {
+          lo = l1;
+          hi = h1;
+          if (mode == M_LAST) j += 1;
+        }
+        finish = true;
+        break;
+      }
+      case S_SA: {
+        const uint64_t e = vc;
+        const uint64_t pos = e & kPosMask, run = e >> kPosBits;
+        const uint32_t rem = L - j;
+        aux |= 1u << 16;  // tried
+        if (e != kNoPosition && run > (uint64_t)rem && pos >= (uint64_t)rem) {
+          p = pos;
+          st = S_CMP;
+          break;
+        }
+        goto choose_step;
+      }
+      case S_CMP: {
+        // bases [j, min(L, end of the read's 64-base piece)) against the text at x0.. (device_index.hip: text-jump)
+        const uint64_t x0 = ix.n - 1 - p;
+        uint64_t t0, t1, r0, r1;
+        sm_funnel128(u64_of(va.x, va.y), u64_of(va.z, va.w), u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), (uint32_t)(x0 & 63), t0, t1);
+        sm_funnel128(w_lo, w_hi, 0, 0, j & 63u, r0, r1);
+        const uint32_t piece_end = (j | 63u) + 1u;
+        const uint32_t stop = piece_end < L ? piece_end : L;
+        const uint32_t nb = stop - j;  // 1..64
+        uint64_t d0 = r0 ^ t0, d1 = r1 ^ t1;
+        if (nb < 32u) d0 &= (1ull << (2 * nb)) - 1ull;
+        if (nb <= 32u) d1 = 0;
+        else if (nb < 64u) d1 &= (1ull << (2 * (nb - 32u))) - 1ull;
+        uint32_t t = nb;
+        if (d0) t = (uint32_t)(__ffsll((unsigned long long)d0) - 1) >> 1;
+        else if (d1) t = 32u + ((uint32_t)(__ffsll((unsigned long long)d1) - 1) >> 1);
+        j += t;
+        p -= t;
+        if (t < nb) {
+          st = S_MISROW;  // the chain dies at base j: exec_exact_match on the row of text position p
+        } else if (j == L) {
+          lo = vc;  // row_tab[p]: the row the chain ends on
+          hi = lo + 1;
+          aux |= 1u << 17;  // located: the position is p
+          finish = true;
+        } else {
+          w_lo = u64_of(vr.x, vr.y);  // next piece of the read
+          w_hi = u64_of(vr.z, vr.w);
+        }
+        break;
+      }
+      case S_MISROW: {
+        lo = vc;
+        hi = lo + 1;
+        const uint32_t c = ((uint32_t)((j & 32u ? w_hi : w_lo) >> (2 * (j & 31u))) & 3u) ^ 3u;
+        aux = (aux & ~0x3ffu) | c | (M_DEAD << 8);
+        st = S_LF1;
+        break;
+      }
+      case S_REFETCH: {
+        w_lo = u64_of(vr.x, vr.y);
+        w_hi = u64_of(vr.z, vr.w);
+        goto choose_step;
+      }
+      case S_LOCATE: {
+        p = vc & kPosMask;
+        if (vc == kNoPosition) aux |= 1u << 18;  // the upstream locate finds nothing
+        aux |= 1u << 17;
+        finish = true;
+        break;
+      }
+      default:
+        break;
+    }
+    goto consumed;
+
+  after_step:
+    // both ends of a two-base step are known (t_lo, t_hi)
+    if (t_lo >= t_hi) {
+      aux = (aux & ~0x3ffu) | ((aux & 15u) >> 2) | (M_REPLAY << 8);  // replay the first base alone
+      st = S_LF1;
+      goto consumed;
+    }
+    lo = t_lo;
+    hi = t_hi;
+    j += 2;
+  after_interval_update:
+    if (lo >= hi) {
+      finish = true;
+      goto consumed;
+    }
+  choose_step:
+    // what the read needs next (searcher.hpp:406-410: one exec_exact_match per remaining base while lo < hi)
+    if (j >= L) {
+      finish = true;
+    } else if ((j & 63u) == 0 && j >= 64u && !(aux & (1u << 19))) {
+      aux |= 1u << 19;  // w must hold the piece j is in before anything looks at the next bases
+      st = S_REFETCH;
+    } else if (hi - lo == 1 && !(aux & (1u << 16))) {
+      st = S_SA;
+    } else {
+      aux &= ~(1u << 19);
+      const uint64_t wsel = (j & 32u) ? w_hi : w_lo;
+      if (j + 1 == L) {
+        const uint32_t c = ((uint32_t)(wsel >> (2 * (j & 31u))) & 3u) ^ 3u;
+        aux = (aux & ~0x3ffu) | c | (M_LAST << 8);
+        st = S_LF1;
+      } else {
+        const uint32_t two = ((uint32_t)(wsel >> (2 * (j & 31u))) & 15u) ^ 15u;  // complement: the query is RC(read)
+        aux = (aux & ~0x3ffu) | ((two & 3u) << 2) | (two >> 2);                  // x = first prepended base, y = second
+        st = S_STEP_LO;
+      }
+    }
+
+  consumed:
+    if (finish) {
+      // suppression (searcher.hpp:415), locate of a size-1 interval, filters, output
+      const uint64_t m = hi > lo ? hi - lo : 0;
+      if (m == 1 && m <= a.limit && !(aux & (1u << 17))) {
+        st = S_LOCATE;
+      } else {
+        int32_t nh = 0;
+        uint64_t first_hit = 0;
+        if (m > a.limit) {
+          flags |= SBWT_RF_SUPPRESSED;
+        } else if (m == 1) {
+          sbwt_hit h;
+          if (!(aux & (1u << 18)) && sm_push_position(ix, T, p, L, a.strand, &h)) {
+            a.hits[r] = h;  // unique hits live at the read's own index
+            first_hit = r;
+            nh = 1;
+          }
+        } else if (m > 1) {
+          // multi-hit read: reserve m slots behind the first n_reads and hand the read to k_multi
+          const uint64_t slot = a.n_reads + atomicAdd(a.multi_slots, (unsigned long long)m);
+          if (slot + m <= a.hits_cap) {
+            first_hit = slot;
+            const unsigned long long q = atomicAdd(a.multi_count, 1ull);
+            a.multi_queue[q] = (uint32_t)r;
+          } else {
+            atomicOr(a.overflow, 1u);
+          }
+        }
+        sbwt_read_result res;
+        res.sa_lo = lo;
+        res.sa_hi = hi;
+        res.first_hit = first_hit;
+        res.nh = nh;
+        res.flags = flags;
+        a.results[r] = res;
+        st = S_DONE;
+      }
+    }
+  }
+}
+
+}  // namespace sbwt
