@@ -536,6 +536,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     sa.multi_count = &c->d_ctr->multi_count;
     sa.overflow = &c->d_ctr->overflow;
     sa.multi_queue = c->d_queue;
+    sa.dbg = getenv("SBWT_SM_DBG") ? (uint32_t)atoi(getenv("SBWT_SM_DBG")) : 0u;
     const bool lds = c->sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);

@@ -31,6 +31,7 @@ enum SmState : uint32_t {
   S_MISROW,     // row of the text position a comparison died at
   S_REFETCH,    // next 64-base piece of the read (stepping across a piece boundary; reads longer than 64 only)
   S_LOCATE,     // sa_full[lo] of a finished size-1 interval
+  S_FIN,        // nothing to load: the search of a prefetched read was over at once
 };
 enum SmMode : uint32_t { M_LAST = 0, M_REPLAY = 1, M_DEAD = 2 };
 
@@ -61,6 +62,8 @@ __device__ __forceinline__ bool sm_push_position(const DeviceIndex& ix, const Sm
   return true;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
@@ -86,11 +89,22 @@ struct SmArgs {
   unsigned long long* multi_count;
   unsigned int* overflow;
   uint32_t* multi_queue;
+  uint32_t dbg;  // experiment switches (SBWT_SM_DBG): 1 = no record prefetch, 2 = no prefix prefetch
 };
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
 constexpr uint32_t kSmMaxSuper = 16;    // superblocks of sb_abs staged in LDS (2^35 suffixes)
 constexpr uint32_t kFlagInvalidSm = 0x80000000u;
+
+// aux bits above the state-private low 10
+constexpr uint32_t A_TRIED = 1u << 16;    // sa_full was consulted for the text comparison
+constexpr uint32_t A_LOCATED = 1u << 17;  // p holds the final text position
+constexpr uint32_t A_NOPOS = 1u << 18;    // the upstream locate reports nothing for this row
+constexpr uint32_t A_PIECE = 1u << 19;    // w holds the read piece j is in (set by S_REFETCH)
+constexpr uint32_t A_HAVE_W = 1u << 20;   // the lane's NEXT read is prefetched (nw_lo, nw_hi, nL)
+constexpr uint32_t A_HAVE_K = 1u << 21;   // ... and so is its search-prefix entry (nk)
+constexpr uint32_t A_REQ_W = 1u << 22;    // prefetch in flight this iteration
+constexpr uint32_t A_REQ_K = 1u << 23;
 
 template <bool kLds>
 __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
@@ -108,41 +122,76 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     __syncthreads();
     T.chr = s_chr; T.npos_key = s_nk; T.npos_val = s_nv; T.sb_abs = s_sb;
   }
+  // the wave's contiguous range of reads; lane l owns reads begin + l, begin + l + 64, ...
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t lane_lt = (1ull << lane) - 1ull;
-  // the wave's contiguous range of reads
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   uint64_t chunk = (a.n_reads + n_waves - 1) / n_waves;
   chunk = (chunk + 63) & ~63ull;
-  uint64_t next = wave * chunk;
-  const uint64_t range_end = next + chunk < a.n_reads ? next + chunk : a.n_reads;
+  const uint64_t range_begin = wave * chunk;
+  const uint64_t range_end = range_begin + chunk < a.n_reads ? range_begin + chunk : a.n_reads;
+  const uint32_t K = ix.kmer_order;
+  const uint32_t kmask = K >= 16u ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+  const uint32_t max_len = a.wpr * 16u;
 
-  // lane state
-  uint32_t st = S_DONE, L = 0, j = 0, aux = 0;  // aux: code (steps) / base c (LF1) | mode << 8 | tried << 16 | located << 17
-  uint64_t r = 0, lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0;
-  uint32_t flags = 0;
+  // lane state.  A lane holds its current read r and has RESERVED its next one, rn: lanes that finish in the same
+  // iteration reserve consecutive reads (ballot order), so the records they prefetch and, since such lanes tend to
+  // finish together again, the results they write fall into the same lines.
+  uint64_t r = range_begin + lane, rn = r + 64;
+  uint64_t next = range_begin + 128;  // wave-uniform: first unreserved read
+  uint32_t st = r < range_end ? S_FETCH : S_IDLE;
+  bool reserve = false;
+  uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0;
+  uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0, nw_lo = 0, nw_hi = 0, nk = 0;
 
-  for (;;) {
-    // ---- refill: finished lanes take the next reads of the range, in lane order
-    {
-      const bool want = st == S_DONE;
-      const uint64_t wm = __ballot(want);
-      if (wm) {
-        if (want) {
-          const uint64_t cand = next + (uint64_t)__popcll(wm & lane_lt);
-          if (cand < range_end) {
-            r = cand;
-            st = S_FETCH;
-            flags = 0;
-            aux = 0;
-          } else {
-            st = S_IDLE;
-          }
-        }
-        next += (uint64_t)__popcll(wm);
+  // interval after the search prefix, from a kmer_tab entry (device_layout.h)
+  auto apply_prefix = [&](uint64_t e) {
+    const uint64_t width = e >> kPosBits;
+    if (width == kKmerWide) {  // not memoised (interval wider than an entry holds): the 12-mer pair, read here
+      const uint32_t kmer = (~(uint32_t)w_lo) & 0xFFFFFFu;
+      lo = ix.c_functions[kmer];
+      hi = ix.c_functions[kmer + 1];
+    } else {
+      lo = e & kPosMask;
+      hi = lo + width;
+      j = K;
+    }
+  };
+  // what the read needs next (searcher.hpp:406-410: one exec_exact_match per remaining base while lo < hi);
+  // returns true when the search is over
+  auto choose = [&]() -> bool {
+    if (lo >= hi || j >= L) return true;
+    if ((j & 63u) == 0 && j >= 64u && !(aux & A_PIECE)) {
+      aux |= A_PIECE;  // w must hold the piece j is in before anything looks at the next bases
+      st = S_REFETCH;
+    } else if (hi - lo == 1 && !(aux & A_TRIED)) {
+      st = S_SA;
+    } else {
+      aux &= ~A_PIECE;
+      const uint64_t wsel = (j & 32u) ? w_hi : w_lo;
+      if (j + 1 == L) {
+        const uint32_t c = ((uint32_t)(wsel >> (2 * (j & 31u))) & 3u) ^ 3u;
+        aux = (aux & ~0x3ffu) | c | (M_LAST << 8);
+        st = S_LF1;
+      } else {
+        const uint32_t two = ((uint32_t)(wsel >> (2 * (j & 31u))) & 15u) ^ 15u;  // complement: the query is RC(read)
+        aux = (aux & ~0x3ffu) | ((two & 3u) << 2) | (two >> 2);                  // x = first prepended base, y = second
+        st = S_STEP_LO;
       }
-      if (!__any(st != S_IDLE)) break;
+    }
+    return false;
+  };
+
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  for (;;) {
+    if (!__any(st != S_IDLE)) break;
+    {
+      const uint64_t wm = __ballot(reserve);
+      if (wm) {
+        if (reserve) rn = next + (uint64_t)__popcll(wm & lane_lt);
+        next += (uint64_t)__popcll(wm);
+        reserve = false;
+      }
     }
     const uint32_t* rp = a.packed + r * (uint64_t)a.wpr;
 
@@ -158,19 +207,22 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint64_t* pe = idle8;  // 8 B
     const uint32_t* pd = a.packed;  // 4 B
     bool pair = false;           // S_KMER through the c_functions pair
+    bool free_r = true, free_e = true;
     switch (st) {
       case S_FETCH:
         pr = reinterpret_cast<const uint4*>(rp);
         pd = a.lens + r;
+        free_r = false;
         break;
       case S_KMER: {
         const uint32_t cw = ~(uint32_t)w_lo;  // complemented codes of bases 0..15
-        if (ix.kmer_tab && L >= ix.kmer_order) {
-          pc = ix.kmer_tab + (ix.kmer_order == 16u ? cw : (cw & ((1u << (2 * ix.kmer_order)) - 1u)));
+        if (ix.kmer_tab && L >= K) {
+          pc = ix.kmer_tab + (cw & kmask);
         } else {
           pc = ix.c_functions + (cw & 0xFFFFFFu);
           pe = pc + 1;
           pair = true;
+          free_e = false;
         }
         break;
       }
@@ -189,6 +241,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         pc = &bl->cnt[aux & 3u];
         pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
         pe = &bh->cnt[aux & 3u];
+        free_e = false;
         break;
       }
       case S_SA:
@@ -201,8 +254,12 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         pa = t4;
         pb = t4 + 1;
         const uint32_t piece_end = (j | 63u) + 1u;
-        if (piece_end >= L) pc = ix.row_tab + (p - (uint64_t)(L - j));   // last chunk: the final row
-        else pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
+        if (piece_end >= L) {
+          pc = ix.row_tab + (p - (uint64_t)(L - j));  // last chunk: the final row
+        } else {
+          pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
+          free_r = false;
+        }
         break;
       }
       case S_MISROW:
@@ -210,9 +267,24 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         break;
       case S_REFETCH:
         pr = reinterpret_cast<const uint4*>(rp) + (j >> 6);
+        free_r = false;
         break;
-      default:
+      default:  // S_FIN, S_IDLE
         break;
+    }
+    // the lane's NEXT read rides in slots this state leaves idle: first its record (16 B + the aligned 8 bytes
+    // holding its length), then its search-prefix entry, so that it starts at its first step
+    if (st != S_IDLE && free_e) {
+      if (!(aux & A_HAVE_W)) {
+        if (free_r && rn + 1 < a.n_reads && rn < range_end && !(a.dbg & 1u)) {
+          pr = reinterpret_cast<const uint4*>(a.packed + rn * (uint64_t)a.wpr);
+          pe = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(a.lens + rn) & ~(uintptr_t)7);
+          aux |= A_REQ_W;
+        }
+      } else if (!(aux & A_HAVE_K) && ix.kmer_tab && nL >= K && nL <= max_len && !(a.dbg & 2u)) {
+        pe = ix.kmer_tab + ((~(uint32_t)nw_lo) & kmask);
+        aux |= A_REQ_K;
+      }
     }
     // The wave barriers are no instructions; being convergent they keep the compiler from duplicating the loads
     // into the per-state branches on either side, which would put a memory wait inside every branch.
@@ -222,6 +294,16 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint32_t vd = *pd;
     __builtin_amdgcn_wave_barrier();
 
+    if (aux & A_REQ_W) {
+      nw_lo = u64_of(vr.x, vr.y);
+      nw_hi = u64_of(vr.z, vr.w);
+      nL = (reinterpret_cast<uintptr_t>(a.lens + rn) & 4) ? (uint32_t)(ve >> 32) : (uint32_t)ve;
+      aux = (aux | A_HAVE_W) & ~A_REQ_W;
+    } else if (aux & A_REQ_K) {
+      nk = ve;
+      aux = (aux | A_HAVE_K) & ~A_REQ_K;
+    }
+
     // ---- consume
     bool finish = false;  // the search part of the read is over: lo/hi final
     switch (st) {
@@ -230,7 +312,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         w_lo = u64_of(vr.x, vr.y);
         w_hi = u64_of(vr.z, vr.w);
         j = kKmer;
-        if (L < (uint32_t)kKmer || L > a.wpr * 16u) {
+        if (L < (uint32_t)kKmer || L > max_len) {
           flags = kFlagInvalidSm;
           lo = hi = 0;
           finish = true;
@@ -244,42 +326,47 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = vc;
           hi = ve;
         } else {
-          const uint64_t width = vc >> kPosBits;
-          if (width == kKmerWide) {  // not memoised (interval wider than an entry holds): the 12-mer pair, read here
-            const uint32_t kmer = (~(uint32_t)w_lo) & 0xFFFFFFu;
-            lo = ix.c_functions[kmer];
-            hi = ix.c_functions[kmer + 1];
-          } else {
-            lo = vc & kPosMask;
-            hi = lo + width;
-            j = ix.kmer_order;
-          }
+          apply_prefix(vc);
         }
-        goto after_interval_update;
-      }
-      case S_STEP_LO: {
-        // exec_exact_match (searcher.hpp:102-105) for two bases; aux & 15 = code
-        const uint32_t code = aux & 15u;
-        const uint64_t blk = lo >> 6;
-        const uint64_t q0 = u64_of(va.x, va.y), q1 = u64_of(va.z, va.w), q2 = u64_of(vb.x, vb.y), q3 = u64_of(vb.z, vb.w);
-        const uint64_t mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
-        const uint64_t base = T.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code] + vd;
-        t_lo = base + (uint64_t)__popcll(mask & below((uint32_t)(lo & 63))) - rank2_correction(ix, code, lo);
-        if (((hi - 1) >> 6) == blk) {
-          t_hi = base + (uint64_t)__popcll(mask & below((uint32_t)(hi - (blk << 6)))) - rank2_correction(ix, code, hi);
-          goto after_step;
-        }
-        st = S_STEP_HI;
+        finish = choose();
         break;
       }
+      case S_STEP_LO:
       case S_STEP_HI: {
+        // exec_exact_match (searcher.hpp:102-105) for two bases; aux & 15 = code.  One block serves the end it
+        // belongs to, and the other end too when that one lies in the same block.
         const uint32_t code = aux & 15u;
-        const uint64_t blk = hi >> 6;
+        const bool second = st == S_STEP_HI;
+        const uint64_t x = second ? hi : lo;
+        const uint64_t blk = x >> 6;
         const uint64_t q0 = u64_of(va.x, va.y), q1 = u64_of(va.z, va.w), q2 = u64_of(vb.x, vb.y), q3 = u64_of(vb.z, vb.w);
         const uint64_t mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
         const uint64_t base = T.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code] + vd;
-        t_hi = base + (uint64_t)__popcll(mask & below((uint32_t)(hi & 63))) - rank2_correction(ix, code, hi);
-        goto after_step;
+        const uint64_t vx = base + (uint64_t)__popcll(mask & below((uint32_t)(x & 63))) - rank2_correction(ix, code, x);
+        bool both = second;
+        if (second) {
+          t_hi = vx;
+        } else {
+          t_lo = vx;
+          if (((hi - 1) >> 6) == blk) {
+            t_hi = base + (uint64_t)__popcll(mask & below((uint32_t)(hi - (blk << 6)))) - rank2_correction(ix, code, hi);
+            both = true;
+          } else {
+            st = S_STEP_HI;
+          }
+        }
+        if (both) {
+          if (t_lo >= t_hi) {
+            aux = (aux & ~0x3ffu) | (code >> 2) | (M_REPLAY << 8);  // replay the first base alone
+            st = S_LF1;
+          } else {
+            lo = t_lo;
+            hi = t_hi;
+            j += 2;
+            finish = choose();
+          }
+        }
+        break;
       }
       case S_LF1: {
         // get_occ_using_jbwt + c_function for base c on both ends
@@ -305,13 +392,14 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         const uint64_t e = vc;
         const uint64_t pos = e & kPosMask, run = e >> kPosBits;
         const uint32_t rem = L - j;
-        aux |= 1u << 16;  // tried
+        aux |= A_TRIED;
         if (e != kNoPosition && run > (uint64_t)rem && pos >= (uint64_t)rem) {
           p = pos;
           st = S_CMP;
-          break;
+        } else {
+          finish = choose();
         }
-        goto choose_step;
+        break;
       }
       case S_CMP: {
         // bases [j, min(L, end of the read's 64-base piece)) against the text at x0.. (device_index.hip: text-jump)
@@ -336,7 +424,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         } else if (j == L) {
           lo = vc;  // row_tab[p]: the row the chain ends on
           hi = lo + 1;
-          aux |= 1u << 17;  // located: the position is p
+          aux |= A_LOCATED;  // the position is p
           finish = true;
         } else {
           w_lo = u64_of(vr.x, vr.y);  // next piece of the read
@@ -355,63 +443,27 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       case S_REFETCH: {
         w_lo = u64_of(vr.x, vr.y);
         w_hi = u64_of(vr.z, vr.w);
-        goto choose_step;
+        finish = choose();
+        break;
       }
       case S_LOCATE: {
         p = vc & kPosMask;
-        if (vc == kNoPosition) aux |= 1u << 18;  // the upstream locate finds nothing
-        aux |= 1u << 17;
+        if (vc == kNoPosition) aux |= A_NOPOS;  // the upstream locate finds nothing
+        aux |= A_LOCATED;
         finish = true;
         break;
       }
+      case S_FIN:
+        finish = true;
+        break;
       default:
         break;
     }
-    goto consumed;
 
-  after_step:
-    // both ends of a two-base step are known (t_lo, t_hi)
-    if (t_lo >= t_hi) {
-      aux = (aux & ~0x3ffu) | ((aux & 15u) >> 2) | (M_REPLAY << 8);  // replay the first base alone
-      st = S_LF1;
-      goto consumed;
-    }
-    lo = t_lo;
-    hi = t_hi;
-    j += 2;
-  after_interval_update:
-    if (lo >= hi) {
-      finish = true;
-      goto consumed;
-    }
-  choose_step:
-    // what the read needs next (searcher.hpp:406-410: one exec_exact_match per remaining base while lo < hi)
-    if (j >= L) {
-      finish = true;
-    } else if ((j & 63u) == 0 && j >= 64u && !(aux & (1u << 19))) {
-      aux |= 1u << 19;  // w must hold the piece j is in before anything looks at the next bases
-      st = S_REFETCH;
-    } else if (hi - lo == 1 && !(aux & (1u << 16))) {
-      st = S_SA;
-    } else {
-      aux &= ~(1u << 19);
-      const uint64_t wsel = (j & 32u) ? w_hi : w_lo;
-      if (j + 1 == L) {
-        const uint32_t c = ((uint32_t)(wsel >> (2 * (j & 31u))) & 3u) ^ 3u;
-        aux = (aux & ~0x3ffu) | c | (M_LAST << 8);
-        st = S_LF1;
-      } else {
-        const uint32_t two = ((uint32_t)(wsel >> (2 * (j & 31u))) & 15u) ^ 15u;  // complement: the query is RC(read)
-        aux = (aux & ~0x3ffu) | ((two & 3u) << 2) | (two >> 2);                  // x = first prepended base, y = second
-        st = S_STEP_LO;
-      }
-    }
-
-  consumed:
     if (finish) {
       // suppression (searcher.hpp:415), locate of a size-1 interval, filters, output
       const uint64_t m = hi > lo ? hi - lo : 0;
-      if (m == 1 && m <= a.limit && !(aux & (1u << 17))) {
+      if (m == 1 && m <= a.limit && !(aux & A_LOCATED)) {
         st = S_LOCATE;
       } else {
         int32_t nh = 0;
@@ -420,7 +472,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           flags |= SBWT_RF_SUPPRESSED;
         } else if (m == 1) {
           sbwt_hit h;
-          if (!(aux & (1u << 18)) && sm_push_position(ix, T, p, L, a.strand, &h)) {
+          if (!(aux & A_NOPOS) && sm_push_position(ix, T, p, L, a.strand, &h)) {
             a.hits[r] = h;  // unique hits live at the read's own index
             first_hit = r;
             nh = 1;
@@ -443,7 +495,33 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         res.nh = nh;
         res.flags = flags;
         a.results[r] = res;
-        st = S_DONE;
+
+        // the lane's next read: start as far down its chain as the prefetches allow
+        r = rn;
+        reserve = true;
+        const uint32_t had = aux;
+        aux = 0;
+        flags = 0;
+        if (r >= range_end) {
+          st = S_IDLE;
+        } else if (!(had & A_HAVE_W)) {
+          st = S_FETCH;
+        } else {
+          w_lo = nw_lo;
+          w_hi = nw_hi;
+          L = nL;
+          j = kKmer;
+          if (L < (uint32_t)kKmer || L > max_len) {
+            flags = kFlagInvalidSm;
+            lo = hi = 0;
+            st = S_FIN;
+          } else if (had & A_HAVE_K) {
+            apply_prefix(nk);
+            if (choose()) st = S_FIN;
+          } else {
+            st = S_KMER;
+          }
+        }
       }
     }
   }
