@@ -388,6 +388,7 @@ struct sbwt_ctx {
   uint32_t grid_lds = 0, grid_glb = 0;  // resident workgroups of k_search_phased<true> / k_search_phased<false>
   uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // same for k_search_sm
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
+  size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
   bool use_phased = false;                    // SBWT_KERNEL=phased: the phase-by-phase kernel (kept for A/B timing)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
@@ -431,11 +432,14 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
       c->grid_glb = (uint32_t)(prop.multiProcessorCount * (per_cu_glb > 0 ? per_cu_glb : 1));
     }
     const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
+    const size_t ring_bytes = (size_t)4 * kSmRing * 32;  // four waves per workgroup
+    c->sm_ring_bytes = ring_bytes;
     if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys && n_super <= kSmMaxSuper)
-      c->sm_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super) * sizeof(uint64_t);
+      c->sm_lds_bytes = (((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super + 1) & ~(size_t)1) * sizeof(uint64_t);
     int sm_lds = 0, sm_glb = 0;
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, 0);
+    if (e == hipSuccess)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes + ring_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, ring_bytes);
     if (e == hipSuccess) {
       c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
       c->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
@@ -540,8 +544,8 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     const bool lds = c->sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);
-    if (lds) k_search_sm<true><<<grid, 256, c->sm_lds_bytes, c->stream>>>(d, sa);
-    else k_search_sm<false><<<grid, 256, 0, c->stream>>>(d, sa);
+    if (lds) k_search_sm<true><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
+    else k_search_sm<false><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
     SBWT_LAUNCHED();
   }
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));

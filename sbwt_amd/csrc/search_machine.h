@@ -32,6 +32,7 @@ enum SmState : uint32_t {
   S_REFETCH,    // next 64-base piece of the read (stepping across a piece boundary; reads longer than 64 only)
   S_LOCATE,     // sa_full[lo] of a finished size-1 interval
   S_FIN,        // nothing to load: the search of a prefetched read was over at once
+  S_START,      // between reads: waits for room in the result ring, then starts its reserved read
 };
 enum SmMode : uint32_t { M_LAST = 0, M_REPLAY = 1, M_DEAD = 2 };
 
@@ -95,6 +96,35 @@ struct SmArgs {
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
 constexpr uint32_t kSmMaxSuper = 16;    // superblocks of sb_abs staged in LDS (2^35 suffixes)
 constexpr uint32_t kFlagInvalidSm = 0x80000000u;
+constexpr uint32_t kSmRing = 256;       // results staged per wave (LDS, 32 B each) before they are written as whole lines
+// ring entry word 3 ("meta")
+constexpr uint32_t R_NH = 1u, R_RC = 2u, R_MULTI = 4u;  // bits 8.. = flags
+
+// one finished read leaves the ring: lane l writes read first + l, so a wave writes 2 KB of results and 1 KB of hits
+// as whole lines
+__device__ __forceinline__ void sm_flush(const SmArgs& a, const uint4* ring, uint64_t range_begin, uint64_t first,
+                                         uint64_t rd, bool valid) {
+  if (!valid) return;
+  const uint4* e = ring + (size_t)((rd - range_begin) & (kSmRing - 1)) * 2;
+  const uint4 e0 = e[0], e1 = e[1];
+  const uint32_t meta = e1.w;
+  const uint64_t payload = ((uint64_t)e1.y << 32) | e1.x;
+  sbwt_read_result res;
+  res.sa_lo = ((uint64_t)e0.y << 32) | e0.x;
+  res.sa_hi = ((uint64_t)e0.w << 32) | e0.z;
+  res.first_hit = (meta & R_NH) ? rd : ((meta & R_MULTI) ? payload : 0);
+  res.nh = (meta & R_NH) ? 1 : 0;
+  res.flags = ((meta >> 8) & 3u) | (meta & kFlagInvalidSm);
+  a.results[rd] = res;
+  if (meta & R_NH) {  // unique hits live at the read's own index
+    sbwt_hit h;
+    h.pos0 = payload;
+    h.chr_id = e1.z;
+    h.is_rc = (meta & R_RC) ? 1u : 0u;
+    a.hits[rd] = h;
+  }
+  (void)first;
+}
 
 // aux bits above the state-private low 10
 constexpr uint32_t A_TRIED = 1u << 16;    // sa_full was consulted for the text comparison
@@ -122,6 +152,9 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     __syncthreads();
     T.chr = s_chr; T.npos_key = s_nk; T.npos_val = s_nv; T.sb_abs = s_sb;
   }
+  // per-wave ring of finished reads (after the tables; 16-byte aligned)
+  const uint32_t table_words = kLds ? ((ix.n_chr + 2 * ix.n_npos + 16 * n_super + 1) & ~1u) : 0u;
+  uint4* const ring = reinterpret_cast<uint4*>(s_mem + table_words) + (size_t)(threadIdx.x >> 6) * kSmRing * 2;
   // the wave's contiguous range of reads; lane l owns reads begin + l, begin + l + 64, ...
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -141,6 +174,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   uint64_t next = range_begin + 128;  // wave-uniform: first unreserved read
   uint32_t st = r < range_end ? S_FETCH : S_IDLE;
   bool reserve = false;
+  uint64_t flushed = range_begin;  // wave-uniform: results of reads below it are in global memory
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0;
   uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0, nw_lo = 0, nw_hi = 0, nk = 0;
 
@@ -185,6 +219,39 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   const uint64_t lane_lt = (1ull << lane) - 1ull;
   for (;;) {
     if (!__any(st != S_IDLE)) break;
+    // ---- flush: reads are reserved in increasing order, so every read below the lowest one a lane still works
+    // on (or waits to start) is finished; 64 of them at a time leave the ring as whole lines
+    for (;;) {
+      const uint64_t cur = st == S_IDLE ? ~0ull : r;
+      if (flushed + 64 > range_end || __any(cur < flushed + 64)) break;
+      sm_flush(a, ring, range_begin, flushed, flushed + lane, true);
+      flushed += 64;
+    }
+    // ---- start: a lane between reads takes its reserved one once the ring has room for it
+    if (st == S_START && r < flushed + kSmRing) {
+      reserve = true;
+      const uint32_t had = aux;
+      aux = 0;
+      flags = 0;
+      if (!(had & A_HAVE_W)) {
+        st = S_FETCH;
+      } else {
+        w_lo = nw_lo;
+        w_hi = nw_hi;
+        L = nL;
+        j = kKmer;
+        if (L < (uint32_t)kKmer || L > max_len) {
+          flags = kFlagInvalidSm;
+          lo = hi = 0;
+          st = S_FIN;
+        } else if (had & A_HAVE_K) {
+          apply_prefix(nk);
+          if (choose()) st = S_FIN;
+        } else {
+          st = S_KMER;
+        }
+      }
+    }
     {
       const uint64_t wm = __ballot(reserve);
       if (wm) {
@@ -466,65 +533,44 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       if (m == 1 && m <= a.limit && !(aux & A_LOCATED)) {
         st = S_LOCATE;
       } else {
-        int32_t nh = 0;
-        uint64_t first_hit = 0;
+        uint32_t meta = 0;
+        uint64_t payload = 0;  // unique hit: position in its chromosome; multi-hit read: first reserved slot
+        uint32_t chr_id = 0;
         if (m > a.limit) {
           flags |= SBWT_RF_SUPPRESSED;
         } else if (m == 1) {
           sbwt_hit h;
           if (!(aux & A_NOPOS) && sm_push_position(ix, T, p, L, a.strand, &h)) {
-            a.hits[r] = h;  // unique hits live at the read's own index
-            first_hit = r;
-            nh = 1;
+            payload = h.pos0;
+            chr_id = h.chr_id;
+            meta = R_NH | (h.is_rc ? R_RC : 0u);
           }
         } else if (m > 1) {
           // multi-hit read: reserve m slots behind the first n_reads and hand the read to k_multi
           const uint64_t slot = a.n_reads + atomicAdd(a.multi_slots, (unsigned long long)m);
           if (slot + m <= a.hits_cap) {
-            first_hit = slot;
+            payload = slot;
+            meta = R_MULTI;
             const unsigned long long q = atomicAdd(a.multi_count, 1ull);
             a.multi_queue[q] = (uint32_t)r;
           } else {
             atomicOr(a.overflow, 1u);
           }
         }
-        sbwt_read_result res;
-        res.sa_lo = lo;
-        res.sa_hi = hi;
-        res.first_hit = first_hit;
-        res.nh = nh;
-        res.flags = flags;
-        a.results[r] = res;
+        // flags: bits 0..1 and bit 31 are in use
+        meta |= ((flags & 3u) << 8) | (flags & kFlagInvalidSm);
+        uint4* e = ring + (size_t)((r - range_begin) & (kSmRing - 1)) * 2;
+        e[0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        e[1] = make_uint4((uint32_t)payload, (uint32_t)(payload >> 32), chr_id, meta);
 
-        // the lane's next read: start as far down its chain as the prefetches allow
+        // the lane's next read is the one it reserved; it starts at the top of the loop
         r = rn;
-        reserve = true;
-        const uint32_t had = aux;
-        aux = 0;
-        flags = 0;
-        if (r >= range_end) {
-          st = S_IDLE;
-        } else if (!(had & A_HAVE_W)) {
-          st = S_FETCH;
-        } else {
-          w_lo = nw_lo;
-          w_hi = nw_hi;
-          L = nL;
-          j = kKmer;
-          if (L < (uint32_t)kKmer || L > max_len) {
-            flags = kFlagInvalidSm;
-            lo = hi = 0;
-            st = S_FIN;
-          } else if (had & A_HAVE_K) {
-            apply_prefix(nk);
-            if (choose()) st = S_FIN;
-          } else {
-            st = S_KMER;
-          }
-        }
+        st = r < range_end ? S_START : S_IDLE;
       }
     }
   }
+  // what is left in the ring
+  for (; flushed < range_end; flushed += 64) sm_flush(a, ring, range_begin, flushed, flushed + lane, flushed + lane < range_end);
 }
 
 }  // namespace sbwt
