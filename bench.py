@@ -189,19 +189,29 @@ def main():
     res_np = np.frombuffer(results.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
     mapped = int((res_np["nh"] > 0).sum())
     multi = int(((res_np["sa_hi"] - res_np["sa_lo"]) > 1).sum())
-    # algorithmic bytes of ONE k_search launch for THIS layout (DESIGN.md "bytes per read"):
-    # 16 B c_functions pair + 128 B per two-base step + 64 B for an odd last base + 8 B sa_full
-    # + 20 B read record/length in + 32 B result + 16 B hit out
-    steps2 = (L - 12) // 2
-    per_read = 16 + 128 * steps2 + 64 * ((L - 12) & 1) + 8 + (wpr * 4 + 4) + 32 + 16
-    algo_bytes = per_read * n_reads
+    # Algorithmic bytes of ONE k_search launch: the search is a chain of random accesses
+    # into index tables far larger than any cache, and HBM serves such an access as one 128-byte line whatever
+    # part of it is used, so the unit is the line: 128 B x (index lines the reads of the batch need, counted by
+    # the kernel itself: search-prefix entry, two-base blocks, memoised locate, text comparison, final row)
+    # + the streamed bytes (read record + length in, result + hit out).
+    stats = ctx.last_stats()
+    accesses = int(stats[0])
+    streamed = n_reads * (wpr * 4 + 4 + 32) + int(n_hits) * 16
+    algo_bytes = 128 * accesses + streamed
     achieved = algo_bytes / (search_ms * 1e-3) / 1e9
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
-    roofline = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
-                "launch_ms": round(search_ms, 3), "bytes_per_read": per_read,
-                "accesses_per_s_G": round(n_reads * (steps2 + 2) / (search_ms * 1e-3) / 1e9, 2),
-                "gather_roofline_G_per_s": 48.0,
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/profile_final.sh from PMC passes
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9:
+            traffic = t.get("traffic_GB_per_launch")
+    roofline = {"bound": "hbm", "kernel": "k_search_sm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/traffic.json)",
+                "launch_ms": round(search_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
+                "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
+                "index_lines_per_s_G": round(accesses / (search_ms * 1e-3) / 1e9, 2),
+                "gather_roofline_lines_per_s_G": 47.0,
                 "survey_formula_GBps": round(survey_per_read * n_reads / (search_ms * 1e-3) / 1e9, 1)}
 
     cpu = None

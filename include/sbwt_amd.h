@@ -137,10 +137,13 @@ int sbwt_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t n_reads,
 /* Replaces the body of the functor at searcher.hpp:348-352 (start_sbwt_match, searcher.hpp:386-458:
  * reverse complement, 12-mer init :83-96, backward search :102-105, suppression :415, level-0 locate
  * :424-443, find_possible :460-503, push_position :504-539) for a whole batch.  All pointers are DEVICE
- * pointers on the index's device; nothing is copied to or from the host.  results[n_reads],
- * hits[hits_cap]; *n_hits_host (host pointer, may be NULL) receives the number of hits written.
- * limit / strand are `sbwt map -m / -s` (main.cpp:167-168).  Hits of one read are contiguous and in
- * upstream emission order; reads appear in hits[] in no particular order (use first_hit). */
+ * pointers on the index's device; nothing is copied to or from the host.  results[n_reads], hits[hits_cap].
+ * limit / strand are `sbwt map -m / -s` (main.cpp:167-168).
+ * Layout of hits[]: the hit of a read with exactly one surviving hit lives at the read's own index
+ * (first_hit == read index), so hits_cap must be at least n_reads; the lists of multi-hit reads follow behind
+ * the first n_reads slots, each contiguous and in upstream emission order (first_hit says where).  Slots of
+ * reads without a hit are not written.  *n_hits_host (host pointer, may be NULL) receives the number of slots
+ * in use = n_reads + the multi-hit lists; on SBWT_ERR_CAPACITY it is what a retry needs. */
 int sbwt_map_batch_device(sbwt_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_lens, uint64_t n_reads,
                           uint32_t words_per_read, int limit, int strand, sbwt_read_result *d_results,
                           sbwt_hit *d_hits, uint64_t hits_cap, uint64_t *n_hits_host);
@@ -153,6 +156,10 @@ int sbwt_map_batch(sbwt_ctx *ctx, const uint32_t *packed, const uint32_t *lens, 
 /* Milliseconds the kernels of the last sbwt_map_batch* call on this ctx took, measured with HIP events
  * on the ctx stream: [0] whole device pass, [1] search+unique-locate kernel, [2] multi-hit locate. */
 int sbwt_ctx_last_timing(const sbwt_ctx *ctx, float ms[3]);
+/* Counters of the last sbwt_map_batch* call on this ctx: [0] random index accesses the search kernel needed
+ * (one per 128-byte line of an index table; the unit of the gather roofline), [1] reads handed to
+ * the multi-hit locate, [2] hit slots in use, [3] reserved (0).  No upstream counterpart: measurement only. */
+int sbwt_ctx_last_stats(const sbwt_ctx *ctx, uint64_t stats[4]);
 /* raw hipStream_t of the ctx, for callers that want to order their own work after a batch */
 void *sbwt_ctx_stream(const sbwt_ctx *ctx);
 

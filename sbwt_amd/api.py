@@ -83,6 +83,7 @@ def lib():
     L.sbwt_map_batch_device.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_map_batch.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_ctx_last_timing.argtypes = [vp, p(C.c_float * 3)]
+    L.sbwt_ctx_last_stats.argtypes = [vp, p(u64 * 4)]
     L.sbwt_ctx_stream.argtypes = [vp]
     L.sbwt_ctx_stream.restype = vp
     L.sbwt_map_fastq.argtypes = [vp, C.c_char_p, C.c_char_p, i32, i32, i32, p(u64 * 5)]
@@ -249,6 +250,11 @@ class Context:
         ms = (C.c_float * 3)()
         _check(lib().sbwt_ctx_last_timing(self._h, C.byref(ms)))
         return list(ms)
+
+    def last_stats(self):
+        st = (C.c_uint64 * 4)()
+        _check(lib().sbwt_ctx_last_stats(self._h, C.byref(st)))
+        return list(st)
 
     def close(self):
         if self._h:

@@ -29,7 +29,8 @@ struct Counters {
   unsigned long long hit_count;    // slots handed out in hits[] behind the first n_reads (multi-hit reads)
   unsigned long long multi_count;  // reads queued for k_multi
   unsigned int overflow;           // hits[] too small
-  unsigned int pad;
+  unsigned int pad0;
+  unsigned long long index_accesses;  // random index accesses k_search_sm issued (one per 128-byte line it needs)
 };
 
 struct MapArgs {
@@ -52,20 +53,6 @@ struct Frame {  // one activation of find_possible
 };
 
 constexpr uint32_t kFlagInvalid = 0x80000000u;  // read shorter than 12 or longer than its record (never from sbwt_pack_reads)
-
-// 32 bases (64 bits) of a 2-bit packed array starting at base `pos`
-__device__ __forceinline__ uint64_t funnel64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh) {
-  const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
-  return sh ? ((lo >> sh) | ((uint64_t)w2 << (64 - sh))) : lo;
-}
-__device__ __forceinline__ uint64_t text_bits64(const uint32_t* __restrict__ t, uint64_t pos) {
-  const uint64_t wi = pos >> 4;  // textrc is padded by 4 words
-  return funnel64(t[wi], t[wi + 1], t[wi + 2], 2u * (uint32_t)(pos & 15));
-}
-__device__ __forceinline__ uint64_t read_bits64(const uint32_t* __restrict__ rp, uint32_t wpr, uint32_t pos) {
-  const uint32_t wi = pos >> 4;  // never reads past the read's own record
-  return funnel64(rp[wi], wi + 1 < wpr ? rp[wi + 1] : 0u, wi + 2 < wpr ? rp[wi + 2] : 0u, 2u * (pos & 15u));
-}
 
 // searcher.hpp:504-539 for one lane.  chr / npos are the sorted key arrays (global memory or the workgroup's LDS
 // copy).  The upstream test "first and last base fall into the same chromosome / the same N-free segment"
@@ -91,200 +78,6 @@ __device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const 
 __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
                                                    sbwt_hit* out) {
   return push_position_keys(ix, ix.chr_start, ix.npos_key, position, L, strand, out);
-}
-
-// bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
-__device__ __forceinline__ void funnel128(uint64_t q0, uint64_t q1, uint64_t q2, uint64_t q3, uint32_t o,
-                                          uint64_t& c0, uint64_t& c1) {
-  uint32_t sh = 2 * o;
-  if (sh >= 64) { q0 = q1; q1 = q2; q2 = q3; sh -= 64; }
-  c0 = sh ? ((q0 >> sh) | (q1 << (64 - sh))) : q0;
-  c1 = sh ? ((q1 >> sh) | (q2 << (64 - sh))) : q1;
-}
-
-// Phases, chosen so that the lanes of a wave wait on memory together (the walk is latency-bound: throughput is
-// requests in flight over latency, and a lane that idles while its neighbours take a private branch is lost):
-//   1. 12-mer table, then two-base steps while ANY read of the wave still has an interval wider than 1;
-//   2. every read whose interval is one row: sa_full -> (text position, run) -> compare the rest of the read
-//      with the text and fetch the final row, all loads issued together;
-//   3. leftovers (repeats, reads near an LF-inconsistent row or the text start): two-base steps to the end;
-//   4. suppression test, unique-hit position filters (push_position), hit slot, result record.
-constexpr int kNarrowIters = 6;
-constexpr uint32_t kMaxLdsKeys = 2048;  // chr_start + npos_key entries kept in LDS (16 KB); larger maps stay in global memory
-
-// Persistent workgroups: each strides over the batch, so the filter tables are staged in LDS once per workgroup.
-template <bool kLds>
-__global__ __launch_bounds__(256) void k_search_phased(const DeviceIndex ix, const MapArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
-  const uint64_t* chr = ix.chr_start;
-  const uint64_t* npos = ix.npos_key;
-  if (kLds) {
-    for (uint32_t k = threadIdx.x; k < ix.n_chr + ix.n_npos; k += blockDim.x)
-      s_keys[k] = k < ix.n_chr ? ix.chr_start[k] : ix.npos_key[k - ix.n_chr];
-    __syncthreads();
-    chr = s_keys;
-    npos = s_keys + ix.n_chr;
-  }
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x; r0 < a.n_reads; r0 += stride) {
-    const uint64_t r = r0 + threadIdx.x;
-    const bool valid = r < a.n_reads;
-    const uint32_t L = valid ? a.lens[r] : 0u;
-    const uint32_t* rp = a.packed + (valid ? r : 0) * (uint64_t)a.wpr;
-    uint64_t lo = 0, hi = 0, located = 0;
-    bool have_located = false;
-    uint32_t flags = 0;
-    uint32_t j = kKmer;
-    bool alive = valid;  // false once the interval died (lo/hi final)
-    if (valid && (L < (uint32_t)kKmer || L > a.wpr * 16u)) {
-      flags = kFlagInvalid;
-      alive = false;
-    }
-    // bases 0..63; base j sits at bits 2j.  The upstream query is RC(read): walking it from its end is walking
-    // the read from its start with every base complemented (code ^ 3).
-    const uint4 w = *reinterpret_cast<const uint4*>(rp);
-    const uint64_t w_lo = ((uint64_t)w.y << 32) | w.x, w_hi = ((uint64_t)w.w << 32) | w.z;  // bases 0..31, 32..63
-    if (alive) {
-      bool memo = false;
-      if (ix.kmer_tab && L >= ix.kmer_order) {
-        // the first kmer_order bases at once (device_layout.h: kmer_tab)
-        const uint64_t e = ix.kmer_tab[ix.kmer_order == 16u ? ~w.x : ((~w.x) & ((1u << (2 * ix.kmer_order)) - 1u))];
-        const uint64_t width = e >> kPosBits;
-        if (width != kKmerWide) {
-          lo = e & kPosMask;
-          hi = lo + width;
-          j = ix.kmer_order;
-          memo = true;
-        }
-      }
-      if (!memo) {
-        // init_exact_match (searcher.hpp:83-96): sum_k q[L-12+k] * 4^(11-k) with q[L-12+k] = 3 - read[11-k]
-        const uint32_t kmer = (~w.x) & 0xFFFFFFu;
-        lo = ix.c_functions[kmer];
-        hi = ix.c_functions[kmer + 1];
-      }
-      alive = lo < hi;
-    }
-    // ---- phase 1 (j stays below 32: bases come from w_lo)
-#pragma unroll 1
-    for (int it = 0; it < kNarrowIters; ++it) {
-      const bool act = alive && hi - lo > 1 && j + 1 < L;
-      if (!__any(act)) break;
-      if (act) {
-        alive = step_two_bases(ix, (uint32_t)(w_lo >> (2 * j)) & 15u, lo, hi);
-        if (alive) j += 2;
-      }
-    }
-    // ---- phase 2
-    if (alive && hi - lo == 1 && j < L) {
-      const uint64_t e = ix.sa_full[lo];
-      const uint64_t p = e & kPosMask, run = e >> kPosBits;
-      const uint32_t rem = L - j;
-      if (e != kNoPosition && run > (uint64_t)rem && p >= (uint64_t)rem) {
-        const uint64_t x0 = ix.n - 1 - p;            // read[j + t] continues the match iff it equals textrc[x0 + t]
-        const uint64_t row_end = ix.row_tab[p - rem];  // needed unless a base differs; fetched alongside the text
-        uint64_t d0, d1 = 0;
-        if (L <= 64u) {
-          // the whole read is in w, and its remainder spans at most two aligned 16-byte pieces of the text
-          const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
-          const uint4 ta = t4[0], tb = t4[1];
-          uint64_t t0, t1;
-          funnel128(((uint64_t)ta.y << 32) | ta.x, ((uint64_t)ta.w << 32) | ta.z, ((uint64_t)tb.y << 32) | tb.x,
-                    ((uint64_t)tb.w << 32) | tb.z, (uint32_t)(x0 & 63), t0, t1);
-          const uint32_t sh = 2 * j;  // 24 <= sh < 64 here (j < 32 after phase 1)
-          d0 = ((w_lo >> sh) | (w_hi << (64 - sh))) ^ t0;
-          d1 = (w_hi >> sh) ^ t1;
-        } else {
-          d0 = read_bits64(rp, a.wpr, j) ^ text_bits64(ix.textrc, x0);
-          if (rem > 32u) d1 = read_bits64(rp, a.wpr, j + 32u) ^ text_bits64(ix.textrc, x0 + 32u);
-        }
-        if (rem < 32u) d0 &= (1ull << (2 * rem)) - 1ull;
-        if (rem <= 32u) d1 = 0;
-        else if (rem < 64u) d1 &= (1ull << (2 * (rem - 32u))) - 1ull;
-        uint32_t t = rem;  // first differing base, rem = none
-        if (d0) t = (uint32_t)(__ffsll((unsigned long long)d0) - 1) >> 1;
-        else if (d1) t = 32u + ((uint32_t)(__ffsll((unsigned long long)d1) - 1) >> 1);
-        else {
-          for (uint32_t u = 64u; u < rem; u += 32u) {  // reads longer than 64 + j bases
-            const uint32_t nb = rem - u < 32u ? rem - u : 32u;
-            uint64_t d = read_bits64(rp, a.wpr, j + u) ^ text_bits64(ix.textrc, x0 + u);
-            if (nb < 32u) d &= (1ull << (2 * nb)) - 1ull;
-            if (d) {
-              t = u + ((uint32_t)(__ffsll((unsigned long long)d) - 1) >> 1);
-              break;
-            }
-          }
-        }
-        if (t == rem) {
-          lo = row_end;
-          hi = lo + 1;
-          located = p - rem;
-          have_located = true;
-        } else {
-          // the chain dies at base j + t: exec_exact_match on the row reached after t matching bases
-          const uint64_t it = t ? ix.row_tab[p - t] : lo;
-          const uint32_t c = ((rp[(j + t) >> 4] >> (2 * ((j + t) & 15u))) & 3u) ^ 3u;
-          lo = lf1(ix, it, c);
-          hi = lf1(ix, it + 1, c);
-          alive = false;
-        }
-        j = L;
-      }
-    }
-    // ---- phase 3
-    while (alive && j < L) {
-      if (j + 1 == L) {  // last base alone
-        const uint32_t c = ((rp[j >> 4] >> (2 * (j & 15u))) & 3u) ^ 3u;
-        const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
-        lo = l1;
-        hi = h1;
-        alive = lo < hi;
-        j += 1;
-      } else {
-        alive = step_two_bases(ix, (rp[j >> 4] >> (2 * (j & 15u))) & 15u, lo, hi);  // j is even: one word
-        if (alive) j += 2;
-      }
-    }
-
-    // ---- phase 4
-    int32_t nh = 0;
-    uint64_t first_hit = 0;
-    bool unique_ok = false;
-    sbwt_hit h;
-    const uint64_t m = hi > lo ? hi - lo : 0;
-    if (m > a.limit) {
-      flags |= SBWT_RF_SUPPRESSED;  // searcher.hpp:415
-    } else if (m == 1) {
-      // the text comparison already knows the position; otherwise one gather of the memoised locate
-      const uint64_t e0 = have_located ? located : ix.sa_full[lo];
-      if (e0 != kNoPosition) unique_ok = push_position_keys(ix, chr, npos, e0 & kPosMask, L, a.strand, &h);
-    }
-    if (unique_ok) {
-      a.hits[r] = h;  // unique hits live at the read's own index
-      first_hit = r;
-      nh = 1;
-    }
-    if (m > 1 && m <= a.limit) {
-      // multi-hit read: reserve m slots and hand the read to k_multi
-      const uint64_t slot = a.n_reads + atomicAdd(&a.ctr->hit_count, (unsigned long long)m);
-      if (slot + m <= a.hits_cap) {
-        first_hit = slot;
-        const unsigned long long q = atomicAdd(&a.ctr->multi_count, 1ull);
-        a.multi_queue[q] = (uint32_t)r;
-      } else {
-        atomicOr(&a.ctr->overflow, 1u);
-      }
-    }
-    if (valid) {
-      sbwt_read_result res;
-      res.sa_lo = lo;
-      res.sa_hi = hi;
-      res.first_hit = first_hit;
-      res.nh = nh;
-      res.flags = flags;
-      a.results[r] = res;
-    }
-  }
 }
 
 // ---- multi-hit locate: the upstream DFS, one lane per queued read -----------------------------
@@ -385,13 +178,12 @@ struct sbwt_ctx {
   uint32_t* d_queue = nullptr;
   Frame* d_stacks = nullptr;
   uint32_t multi_lanes = 0;
-  uint32_t grid_lds = 0, grid_glb = 0;  // resident workgroups of k_search_phased<true> / k_search_phased<false>
   uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // same for k_search_sm
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
-  bool use_phased = false;                    // SBWT_KERNEL=phased: the phase-by-phase kernel (kept for A/B timing)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
+  uint64_t last_stats[3] = {0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -421,16 +213,6 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, ix->device);
-    int per_cu_lds = 0, per_cu_glb = 0;
-    const size_t lds_bytes = (size_t)(ix->d.n_chr + ix->d.n_npos) * sizeof(uint64_t);
-    if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lds, k_search_phased<true>, 256,
-                                                       lds_bytes <= kMaxLdsKeys * sizeof(uint64_t) ? lds_bytes : 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_glb, k_search_phased<false>, 256, 0);
-    if (e == hipSuccess) {
-      c->grid_lds = (uint32_t)(prop.multiProcessorCount * (per_cu_lds > 0 ? per_cu_lds : 1));
-      c->grid_glb = (uint32_t)(prop.multiProcessorCount * (per_cu_glb > 0 ? per_cu_glb : 1));
-    }
     const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
     const size_t ring_bytes = (size_t)4 * kSmRing * 32;  // four waves per workgroup
     c->sm_ring_bytes = ring_bytes;
@@ -444,8 +226,6 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
       c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
       c->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
     }
-    const char* kv = getenv("SBWT_KERNEL");
-    c->use_phased = kv && !strcmp(kv, "phased");
   }
   if (e != hipSuccess) {
     sbwt_ctx_free(c);
@@ -471,6 +251,15 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
 }
 
 extern "C" void* sbwt_ctx_stream(const sbwt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int sbwt_ctx_last_stats(const sbwt_ctx* c, uint64_t stats[4]) {
+  if (!c || !stats) return SBWT_ERR_ARG;
+  stats[0] = c->last_stats[0];
+  stats[1] = c->last_stats[1];
+  stats[2] = c->last_stats[2];
+  stats[3] = 0;
+  return SBWT_OK;
+}
 
 extern "C" int sbwt_ctx_last_timing(const sbwt_ctx* c, float ms[3]) {
   if (!c || !ms) return SBWT_ERR_ARG;
@@ -516,16 +305,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
   const DeviceIndex& d = c->ix->d;
-  if (c->use_phased) {
-    // persistent grid: as many workgroups as the device keeps resident, never more than the batch needs
-    const uint32_t n_keys = d.n_chr + d.n_npos;
-    const bool lds = n_keys <= kMaxLdsKeys;
-    const uint64_t need = (n_reads + 255) / 256;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_lds : c->grid_glb);
-    if (lds) k_search_phased<true><<<grid, 256, n_keys * sizeof(uint64_t), c->stream>>>(d, a);
-    else k_search_phased<false><<<grid, 256, 0, c->stream>>>(d, a);
-    SBWT_LAUNCHED();
-  } else {
+  {
     SmArgs sa;
     sa.packed = d_packed;
     sa.lens = d_lens;
@@ -540,7 +320,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     sa.multi_count = &c->d_ctr->multi_count;
     sa.overflow = &c->d_ctr->overflow;
     sa.multi_queue = c->d_queue;
-    sa.dbg = getenv("SBWT_SM_DBG") ? (uint32_t)atoi(getenv("SBWT_SM_DBG")) : 0u;
+    sa.index_accesses = &c->d_ctr->index_accesses;
     const bool lds = c->sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);
@@ -558,6 +338,9 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   hipEventElapsedTime(&c->last_ms[1], c->ev[0], c->ev[1]);
   hipEventElapsedTime(&c->last_ms[2], c->ev[1], c->ev[2]);
   const uint64_t used = n_reads + c->h_ctr->hit_count;  // one slot per read + the multi-hit lists
+  c->last_stats[0] = c->h_ctr->index_accesses;
+  c->last_stats[1] = c->h_ctr->multi_count;
+  c->last_stats[2] = used;
   if (c->h_ctr->overflow) {
     char msg[160];
     snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided", (unsigned long long)used,

@@ -90,7 +90,7 @@ struct SmArgs {
   unsigned long long* multi_count;
   unsigned int* overflow;
   uint32_t* multi_queue;
-  uint32_t dbg;  // experiment switches (SBWT_SM_DBG): 1 = no record prefetch, 2 = no prefix prefetch
+  unsigned long long* index_accesses;  // tally of random index accesses (for the roofline accounting)
 };
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   uint32_t st = r < range_end ? S_FETCH : S_IDLE;
   bool reserve = false;
   uint64_t flushed = range_begin;  // wave-uniform: results of reads below it are in global memory
+  uint32_t tally = 0;              // random index accesses this lane needed (128-byte lines)
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0;
   uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0, nw_lo = 0, nw_hi = 0, nk = 0;
 
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         break;
       case S_KMER: {
         const uint32_t cw = ~(uint32_t)w_lo;  // complemented codes of bases 0..15
+        tally += 1;
         if (ix.kmer_tab && L >= K) {
           pc = ix.kmer_tab + (cw & kmask);
         } else {
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         pa = reinterpret_cast<const uint4*>(&b->plane[0]);
         pb = reinterpret_cast<const uint4*>(&b->plane[2]);
         pd = &b->cnt[aux & 15u];
+        tally += 1;
         break;
       }
       case S_LF1: {
@@ -309,11 +312,13 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
         pe = &bh->cnt[aux & 3u];
         free_e = false;
+        tally += bl == bh ? 1u : 2u;
         break;
       }
       case S_SA:
       case S_LOCATE:
         pc = ix.sa_full + lo;
+        tally += 1;
         break;
       case S_CMP: {
         const uint64_t x0 = ix.n - 1 - p;  // read[j + t] continues the match iff it equals textrc[x0 + t]
@@ -321,8 +326,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         pa = t4;
         pb = t4 + 1;
         const uint32_t piece_end = (j | 63u) + 1u;
+        const uint64_t x1 = x0 + ((piece_end < L ? piece_end : L) - j) - 1;  // last base compared
+        tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;                     // 512 bases per 128-byte line
         if (piece_end >= L) {
           pc = ix.row_tab + (p - (uint64_t)(L - j));  // last chunk: the final row
+          tally += 1;
         } else {
           pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
           free_r = false;
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       }
       case S_MISROW:
         pc = ix.row_tab + p;
+        tally += 1;
         break;
       case S_REFETCH:
         pr = reinterpret_cast<const uint4*>(rp) + (j >> 6);
@@ -343,14 +352,15 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     // holding its length), then its search-prefix entry, so that it starts at its first step
     if (st != S_IDLE && free_e) {
       if (!(aux & A_HAVE_W)) {
-        if (free_r && rn + 1 < a.n_reads && rn < range_end && !(a.dbg & 1u)) {
+        if (free_r && rn + 1 < a.n_reads && rn < range_end) {
           pr = reinterpret_cast<const uint4*>(a.packed + rn * (uint64_t)a.wpr);
           pe = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(a.lens + rn) & ~(uintptr_t)7);
           aux |= A_REQ_W;
         }
-      } else if (!(aux & A_HAVE_K) && ix.kmer_tab && nL >= K && nL <= max_len && !(a.dbg & 2u)) {
+      } else if (!(aux & A_HAVE_K) && ix.kmer_tab && nL >= K && nL <= max_len) {
         pe = ix.kmer_tab + ((~(uint32_t)nw_lo) & kmask);
         aux |= A_REQ_K;
+        tally += 1;
       }
     }
     // The wave barriers are no instructions; being convergent they keep the compiler from duplicating the loads
@@ -568,6 +578,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         st = r < range_end ? S_START : S_IDLE;
       }
     }
+  }
+  {
+    uint32_t t = tally;
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+    if (lane == 0) atomicAdd(a.index_accesses, (unsigned long long)t);
   }
   // what is left in the ring
   for (; flushed < range_end; flushed += 64) sm_flush(a, ring, range_begin, flushed, flushed + lane, flushed + lane < range_end);
