@@ -1,0 +1,113 @@
+"""GPU: parity at a size the oracle still finishes in seconds, on the shapes of BASELINE.json's other configs:
+36-, 50- and 100-bp reads (configs 2-4) and 18-30-nt reads over an injected repeat family with 2..1500 copies
+(config 5: multi-hit locate, suppression above -m 1000), both strands, a fifth of the reads with one substitution.
+The index is built on the GPU from the packed genome (sbwt_index_build_device); the oracle runs on the
+reference-format tables the same build exports, so both sides see the same index."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_codes(codes):
+    n = len(codes)
+    words = (n + 15) // 16
+    buf = np.zeros(words * 16, dtype=np.uint64)
+    buf[:n] = codes
+    sh = (2 * np.arange(16, dtype=np.uint64))
+    return (buf.reshape(words, 16) << sh).sum(axis=1).astype(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def world(oracle):
+    import torch
+    import sbwt_amd as sb
+    rng = np.random.default_rng(2024)
+    g = 3_000_000
+    codes = rng.integers(0, 4, g).astype(np.uint8)
+    # repeat family: 40 distinct 30-mers with 2..1500 copies each, planted at random non-overlapping slots
+    slots = rng.permutation(g // 64 - 2)[:6000] * 64 + 7
+    fam = rng.integers(0, 4, (40, 30)).astype(np.uint8)
+    copies = [2, 3, 5, 8, 13, 50, 200, 999, 1000, 1001, 1500] + [4] * 29
+    k = 0
+    for f, c in zip(fam, copies):
+        for _ in range(c):
+            codes[slots[k]: slots[k] + 30] = f
+            k += 1
+    chr_start = np.array([0, 1_200_000, 2_100_000], dtype=np.uint64)
+    npos_key = np.array([0, 400_000, 1_200_000, 2_100_000, 2_600_000, g], dtype=np.uint64)
+    npos_val = np.array([1000, 51000, 500, 0, 77, 0], dtype=np.uint64)
+    packed = torch.from_numpy(np.concatenate([pack_codes(codes), np.zeros(4, np.uint32)]).view(np.int32)).cuda()
+    ix, tables = sb.build_index_device(packed.data_ptr(), g, chr_start, npos_key, npos_val, interval=64, device=0,
+                                       want_index=True, want_tables=True)
+    T = tables.contents
+    L_ = oracle.lib()
+    c4 = (C.c_uint64 * 4)(*T.c_function4)
+    h = L_.sbo_index_wrap(T.interval, T.n, T.first_location, T.real_size, C.addressof(c4), T.c_functions, T.occ[0],
+                          T.occ[1], T.occ[2], T.occ[3], T.occ_len, T.jbwt_seq, T.fbwt, T.location_table, T.n_loc,
+                          chr_start.size, chr_start.ctypes.data, npos_key.size, npos_key.ctypes.data,
+                          npos_val.ctypes.data)
+    oix = oracle.OracleIndex(h, keep=(c4, chr_start, npos_key, npos_val))
+    yield sb, ix, oix, codes, fam, rng
+    oix.close()
+    ix.close()
+    sb.host_tables_free(tables)
+
+
+def sample_reads(rng, codes, n, lens, mutate=0.2):
+    g = len(codes)
+    out = []
+    for _ in range(n):
+        L = int(rng.choice(lens))
+        p = int(rng.integers(0, g - L))
+        r = codes[p:p + L].copy()
+        if rng.random() < 0.5:
+            r = 3 - r[::-1]
+        if rng.random() < mutate:
+            q = int(rng.integers(0, L))
+            r[q] = (r[q] + 1 + rng.integers(0, 3)) & 3
+        out.append(bytes(b"ACGT"[c] for c in r))
+    return out
+
+
+def check(sb, ix, oix, reads, limit=1000, strand=2):
+    packed, lens = sb.pack_reads(reads)
+    ctx = sb.Context(ix, len(reads))
+    res, hits = ctx.map_batch(packed, lens, limit=limit, strand=strand)
+    stats = ctx.last_stats()
+    ctx.close()
+    lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand, nthreads=8)
+    np.testing.assert_array_equal(res["sa_lo"], lo)
+    np.testing.assert_array_equal(res["sa_hi"], hi)
+    np.testing.assert_array_equal(res["nh"], nh)
+    # ordered hit lists, all reads at once
+    gi = np.repeat(res["first_hit"], np.maximum(nh, 0)) + (np.arange(int(nh.sum())) - np.repeat(np.cumsum(nh) - nh, nh))
+    oi = np.repeat(first, np.maximum(nh, 0)) + (np.arange(int(nh.sum())) - np.repeat(np.cumsum(nh) - nh, nh))
+    assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+    return res, nh, stats
+
+
+@pytest.mark.parametrize("L", [36, 50, 100])
+def test_fixed_length_reads(world, L):
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 20000, [L])
+    res, nh, stats = check(sb, ix, oix, reads)
+    assert (nh == 1).mean() > 0.7
+    assert stats[0] > 0                                  # the kernel reports its index accesses
+
+
+def test_small_rna_multi_hit_reads(world):
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 8000, list(range(18, 31)))
+    for f in fam:                                        # reads inside the repeat family: 2..1500 hits
+        for a, b in ((0, 30), (0, 18), (5, 27), (12, 30)):
+            s = f[a:b]
+            reads.append(bytes(b"ACGT"[c] for c in s))
+            reads.append(bytes(b"ACGT"[c] for c in (3 - s[::-1])))
+    res, nh, stats = check(sb, ix, oix, reads)
+    assert nh.max() >= 999 and (res["flags"] & sb.RF_SUPPRESSED).any()
+    for limit, strand in ((5, 2), (1000, 0), (1000, 1), (-1, 2)):
+        check(sb, ix, oix, reads[-400:], limit=limit, strand=strand)
