@@ -59,6 +59,10 @@ def make_genome(torch, dev, g, seed):
     for a in range(0, g, step):
         b = min(g, a + step)
         codes[a:b] = torch.randint(0, 4, (b - a,), dtype=torch.uint8, device=dev, generator=gen)
+    return codes, repack(torch, dev, codes, g)
+
+
+def repack(torch, dev, codes, g):
     words = (g + 15) // 16
     packed = torch.zeros(words + 1, dtype=torch.int32, device=dev)
     shifts = (2 * torch.arange(16, device=dev, dtype=torch.int32))
@@ -69,36 +73,66 @@ def make_genome(torch, dev, g, seed):
         hi = min(g, b * 16)
         chunk[: hi - a * 16] = codes[a * 16: hi].to(torch.int32)
         packed[a:b] = (chunk.view(-1, 16) << shifts).sum(dim=1, dtype=torch.int32)
-    return codes, packed
+    return packed
 
 
-def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr):
-    """n_reads error-free reads of length L, strand uniform -> packed int32 [n_reads, wpr], lens int32"""
+def plant_repeats(torch, dev, codes, g, seed, n_families=2000, max_copies=5000):
+    """config 5: n_families distinct 30-mers, family f planted copies[f] times (2..max_copies, log-uniform) at
+    random 64-aligned slots; returns the slot starts (device tensor) so reads can be drawn from them"""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    u = torch.rand(n_families, device=dev, generator=gen)
+    copies = torch.exp(u * float(np.log(max_copies / 2.0))).mul(2.0).long().clamp(2, max_copies)
+    total = int(copies.sum().item())
+    slots = torch.randperm(g // 64 - 2, device=dev, generator=gen)[:total] * 64 + 7
+    fam = torch.randint(0, 4, (n_families, 30), dtype=torch.uint8, device=dev, generator=gen)
+    owner = torch.repeat_interleave(torch.arange(n_families, device=dev), copies)
+    idx = slots[:, None] + torch.arange(30, device=dev)[None, :]
+    codes[idx.reshape(-1)] = fam[owner].reshape(-1)
+    return slots
+
+
+def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=None):
+    """n_reads error-free reads, strand uniform -> packed int32 [n_reads, wpr], lens int32.  Length L, or uniform
+    in min_len..L; with `slots`, half of the reads start inside a planted repeat"""
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     packed = torch.zeros((n_reads, wpr), dtype=torch.int32, device=dev)
+    lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
     shifts = (2 * torch.arange(16, device=dev, dtype=torch.int32))
     ar = torch.arange(L, device=dev, dtype=torch.int64)
     step = 1 << 22
     for a in range(0, n_reads, step):
         b = min(n_reads, a + step)
         pos = torch.randint(0, g - L, (b - a,), device=dev, generator=gen, dtype=torch.int64)
+        if slots is not None:
+            pick = slots[torch.randint(0, slots.numel(), (b - a,), device=dev, generator=gen)]
+            use = torch.randint(0, 2, (b - a,), device=dev, generator=gen).bool()
+            pos = torch.where(use, pick, pos)
         rev = torch.randint(0, 2, (b - a,), device=dev, generator=gen, dtype=torch.int64).bool()
         bases = codes[(pos[:, None] + ar[None, :])].to(torch.int32)          # forward strand
         rc = 3 - bases.flip(1)
         bases = torch.where(rev[:, None], rc, bases)
         buf = torch.zeros((b - a, wpr * 16), dtype=torch.int32, device=dev)
         buf[:, :L] = bases
+        if min_len is not None:
+            ln = torch.randint(min_len, L + 1, (b - a,), device=dev, generator=gen, dtype=torch.int64)
+            lens[a:b] = ln.to(torch.int32)
+            # bases past a read's length are zero in its record, as sbwt_pack_reads leaves them
+            buf *= (torch.arange(wpr * 16, device=dev)[None, :] < ln[:, None]).to(torch.int32)
         packed[a:b] = (buf.view(b - a, wpr, 16) << shifts).sum(dim=2, dtype=torch.int32)
-    lens = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
     return packed, lens
 
 
-def unpack_reads(packed_np, L):
-    """packed uint32 [n, wpr] -> ASCII bytes array [n*L] (numpy, vectorised)"""
-    j = np.arange(L)
+def unpack_reads(packed_np, lens_np):
+    """packed uint32 [n, wpr], lens [n] -> (ASCII bytes of all reads back to back, offsets uint64 [n + 1])"""
+    Lmax = int(lens_np.max())
+    j = np.arange(Lmax)
     codes = (packed_np[:, j >> 4] >> (2 * (j & 15)).astype(np.uint32)) & 3
-    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].reshape(-1)
+    keep = j[None, :] < lens_np[:, None]
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[codes][keep]
+    offsets = np.concatenate([[0], np.cumsum(lens_np.astype(np.uint64))]).astype(np.uint64)
+    return seqs, offsets
 
 
 def main():
@@ -111,6 +145,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--min-len", type=int, default=None, help="reads of length min-len..read-len (config 5)")
+    ap.add_argument("--repeats", action="store_true", help="plant a repeat family, half of the reads inside it (config 5)")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +168,10 @@ def main():
     L = args.read_len
     lens_chr, g, chr_start, npos_key, npos_val = synth_tables(args.scale)
     codes, packed_genome = make_genome(torch, dev, g, seed=38)
+    slots = None
+    if args.repeats:
+        slots = plant_repeats(torch, dev, codes, g, seed=5)
+        packed_genome = repack(torch, dev, codes, g)
     torch.cuda.synchronize()
     t_genome = time.time() - t0
 
@@ -148,7 +188,7 @@ def main():
     wpr = sbwt_amd.words_per_read(L)
     n_reads = args.reads
     t0 = time.time()
-    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr)
+    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots)
     del codes
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
@@ -156,7 +196,7 @@ def main():
 
     res_bytes = n_reads * 32
     results = torch.empty(res_bytes, dtype=torch.uint8, device=dev)
-    hits_cap = n_reads + (1 << 20)
+    hits_cap = n_reads + (1 << 20) if not args.repeats else 80 * n_reads
     hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
     ctx = sbwt_amd.Context(ix, n_reads)
 
@@ -233,22 +273,25 @@ def main():
         probe_n = 20000
         sample_max = 2_000_000
         host_packed = packed[:sample_max].cpu().numpy().view(np.uint32)
-        probe = np.concatenate([unpack_reads(host_packed[:probe_n], L), np.zeros(1, np.uint8)])
+        host_lens = lens[:sample_max].cpu().numpy().astype(np.uint32)
+        pseq, poff = unpack_reads(host_packed[:probe_n], host_lens[:probe_n])
         t1 = time.perf_counter()
-        lo, hi, nh, first, ohits = oix.map_batch_raw(probe, np.arange(probe_n + 1, dtype=np.uint64) * L, probe_n,
-                                                     nthreads=1)
+        lo, hi, nh, first, ohits = oix.map_batch_raw(np.concatenate([pseq, np.zeros(1, np.uint8)]), poff, probe_n, nthreads=1)
         rate1 = probe_n / (time.perf_counter() - t1)
         # parity of the same reads through the GPU path
         gres = res_np[:probe_n]
-        hits_np = np.frombuffer(hits[: int(n_hits) * 16].cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
         ok = bool(np.array_equal(gres["sa_lo"], lo) and np.array_equal(gres["sa_hi"], hi) and np.array_equal(gres["nh"], nh))
-        for r in np.nonzero(nh)[0][:5000]:
-            a = hits_np[int(gres["first_hit"][r]): int(gres["first_hit"][r]) + int(nh[r])]
-            ok = ok and bool(np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]))
+        if ok and int(nh.sum()):
+            # ordered hit lists of the probe reads, gathered on the device (the lists of multi-hit reads lie anywhere)
+            tot = int(nh.sum())
+            within = np.arange(tot) - np.repeat(np.cumsum(nh) - nh, nh)
+            gi = torch.from_numpy((np.repeat(gres["first_hit"], nh) + within).astype(np.int64)).to(dev)
+            ghits = np.frombuffer(hits.view(-1, 16)[gi].cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
+            oi = (np.repeat(first, nh) + within).astype(np.int64)
+            ok = bool(np.array_equal(ghits, ohits[oi]))
         parity = {"reads_checked": probe_n, "identical": ok}
         sample_n = int(min(sample_max, max(probe_n, rate1 * cores * args.cpu_seconds * 0.7)))
-        seqs = unpack_reads(host_packed[:sample_n], L)
-        offsets = (np.arange(sample_n + 1, dtype=np.uint64) * L)
+        seqs, offsets = unpack_reads(host_packed[:sample_n], host_lens[:sample_n])
         t1 = time.perf_counter()
         oix.map_batch_raw(np.concatenate([seqs, np.zeros(1, np.uint8)]), offsets, sample_n, nthreads=cores)
         dt = time.perf_counter() - t1
@@ -263,8 +306,10 @@ def main():
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs), %d x %d-bp exact reads per GPU, "
-                               "both strands, -m 1000 -s 2, inputs resident in HBM" % (g / 1e9, n_reads, L),
+        "config": {"workload": "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s), %d x %s exact reads per GPU, "
+                               "both strands, -m 1000 -s 2, inputs resident in HBM"
+                               % (g / 1e9, ", planted repeat family" if args.repeats else "", n_reads,
+                                  "%d-bp" % L if args.min_len is None else "%d..%d-nt" % (args.min_len, L)),
                    "index_suffixes": int(info.n), "index_hbm_GB": round(info.device_bytes / 1e9, 2),
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu,

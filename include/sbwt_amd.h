@@ -158,7 +158,7 @@ int sbwt_map_batch(sbwt_ctx *ctx, const uint32_t *packed, const uint32_t *lens, 
 int sbwt_ctx_last_timing(const sbwt_ctx *ctx, float ms[3]);
 /* Counters of the last sbwt_map_batch* call on this ctx: [0] random index accesses the search kernel needed
  * (one per 128-byte line of an index table; the unit of the gather roofline), [1] reads handed to
- * the multi-hit locate, [2] hit slots in use, [3] reserved (0).  No upstream counterpart: measurement only. */
+ * the multi-hit locate, [2] hit slots in use, [3] multi-hit reads that needed the depth-first walk.  No upstream counterpart: measurement only. */
 int sbwt_ctx_last_stats(const sbwt_ctx *ctx, uint64_t stats[4]);
 /* raw hipStream_t of the ctx, for callers that want to order their own work after a batch */
 void *sbwt_ctx_stream(const sbwt_ctx *ctx);

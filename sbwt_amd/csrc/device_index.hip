@@ -235,6 +235,13 @@ __global__ __launch_bounds__(256) void k_verify_rows(DeviceIndex ix, const uint6
   const uint64_t p = sa_full[j];
   if (p >= ix.n) return;
   bool bad = row_tab[p] != j;
+  {
+    // a row is sampled exactly when its position is a multiple of the sampling distance (what makes the
+    // depth-first locate report every row of an interval once: multi_locate.h)
+    const Block1* bj = ix.blocks1 + (j >> 6);
+    const bool sampled = (bj->sampled >> (j & 63)) & 1ull;
+    if (sampled != (p % ix.interval == 0)) bad = true;
+  }
   if (!bad && j == ix.first_location) bad = p != 0;  // the '$' row ends every chain: text position 0
   if (!bad && j != ix.first_location) {
     if (p == 0) bad = true;

@@ -31,6 +31,7 @@ struct Counters {
   unsigned int overflow;           // hits[] too small
   unsigned int pad0;
   unsigned long long index_accesses;  // random index accesses k_search_sm issued (one per 128-byte line it needs)
+  unsigned long long dfs_count;       // multi-hit reads k_multi_sort handed on to the depth-first kernel
 };
 
 struct MapArgs {
@@ -80,6 +81,10 @@ __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64
   return push_position_keys(ix, ix.chr_start, ix.npos_key, position, L, strand, out);
 }
 
+}  // namespace sbwt
+#include "multi_locate.h"
+namespace sbwt {
+
 // ---- multi-hit locate: the upstream DFS, one lane per queued read -----------------------------
 struct MultiState {
   const DeviceIndex* ix;
@@ -121,12 +126,13 @@ __device__ __forceinline__ bool scan_sampled(MultiState& S, uint64_t f, uint64_t
 }
 
 __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapArgs a, Frame* __restrict__ stacks,
-                                               uint32_t lanes_total) {
+                                               uint32_t lanes_total, const uint32_t* __restrict__ queue,
+                                               const unsigned long long* __restrict__ queue_count) {
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t qn = a.ctr->multi_count;
+  const uint64_t qn = *queue_count;
   Frame* stack = stacks + (uint64_t)lane_global * ix.interval;  // frames 1 .. interval-1
   for (uint64_t q = lane_global; q < qn; q += lanes_total) {
-    const uint32_t r = a.multi_queue[q];
+    const uint32_t r = queue[q];
     sbwt_read_result res = a.results[r];
     const uint64_t lo = res.sa_lo, hi = res.sa_hi;
     MultiState S;
@@ -176,14 +182,16 @@ struct sbwt_ctx {
   Counters* d_ctr = nullptr;
   Counters* h_ctr = nullptr;  // pinned
   uint32_t* d_queue = nullptr;
+  uint32_t* d_dfs_queue = nullptr;
   Frame* d_stacks = nullptr;
   uint32_t multi_lanes = 0;
-  uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // same for k_search_sm
+  uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // resident workgroups of k_search_sm
+  uint32_t grid_sort = 0;                     // ... of k_multi_sort
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[3] = {0, 0, 0};
+  uint64_t last_stats[4] = {0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -205,6 +213,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) e = hipMalloc(&c->d_ctr, sizeof(Counters));
   if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, sizeof(Counters));
   if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&c->d_dfs_queue, max_reads * sizeof(uint32_t));
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
   c->multi_lanes = 256u * 1024u;
   if (c->multi_lanes > max_reads) c->multi_lanes = (uint32_t)((max_reads + 255) / 256 * 256);
@@ -222,6 +231,9 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     if (e == hipSuccess)
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes + ring_bytes);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, ring_bytes);
+    int sort_per_cu = 0;
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort, 256, 0);
+    c->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
     if (e == hipSuccess) {
       c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
       c->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
@@ -242,6 +254,7 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_ctr);
   if (c->h_ctr) hipHostFree(c->h_ctr);
   hipFree(c->d_queue);
+  hipFree(c->d_dfs_queue);
   hipFree(c->d_stacks);
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits);
   for (int k = 0; k < 3; ++k)
@@ -257,7 +270,7 @@ extern "C" int sbwt_ctx_last_stats(const sbwt_ctx* c, uint64_t stats[4]) {
   stats[0] = c->last_stats[0];
   stats[1] = c->last_stats[1];
   stats[2] = c->last_stats[2];
-  stats[3] = 0;
+  stats[3] = c->last_stats[3];
   return SBWT_OK;
 }
 
@@ -329,7 +342,23 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     SBWT_LAUNCHED();
   }
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
-  k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(c->ix->d, a, c->d_stacks, c->multi_lanes);
+  {
+    // multi-hit reads: gather + sort where the tables allow it, the upstream depth-first walk for the rest
+    MultiSortArgs ms;
+    ms.lens = d_lens;
+    ms.strand = strand;
+    ms.results = d_results;
+    ms.hits = d_hits;
+    ms.queue = c->d_queue;
+    ms.queue_count = &c->d_ctr->multi_count;
+    ms.dfs_queue = c->d_dfs_queue;
+    ms.dfs_count = &c->d_ctr->dfs_count;
+    k_multi_sort<<<c->grid_sort, 256, 0, c->stream>>>(d, ms);
+    SBWT_LAUNCHED();
+    k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(d, a, c->d_stacks, c->multi_lanes, c->d_dfs_queue,
+                                                         &c->d_ctr->dfs_count);
+    SBWT_LAUNCHED();
+  }
   SBWT_HIP(hipEventRecord(c->ev[2], c->stream));
   SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
   SBWT_HIP(hipStreamSynchronize(c->stream));
@@ -340,6 +369,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   const uint64_t used = n_reads + c->h_ctr->hit_count;  // one slot per read + the multi-hit lists
   c->last_stats[0] = c->h_ctr->index_accesses;
   c->last_stats[1] = c->h_ctr->multi_count;
+  c->last_stats[3] = c->h_ctr->dfs_count;
   c->last_stats[2] = used;
   if (c->h_ctr->overflow) {
     char msg[160];

@@ -23,8 +23,12 @@ def pack_codes(codes):
 
 @pytest.fixture(scope="module")
 def world(oracle):
-    import torch
     import sbwt_amd as sb
+    sb.device_count()                      # loads libsbwt_amd.so and, with it, the HIP runtime
+    hip = C.CDLL("libamdhip64.so.7")       # the same runtime (no torch here: a second HIP runtime in one process
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]   # that initialises after the first sees no GPU)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     rng = np.random.default_rng(2024)
     g = 3_000_000
     codes = rng.integers(0, 4, g).astype(np.uint8)
@@ -40,9 +44,13 @@ def world(oracle):
     chr_start = np.array([0, 1_200_000, 2_100_000], dtype=np.uint64)
     npos_key = np.array([0, 400_000, 1_200_000, 2_100_000, 2_600_000, g], dtype=np.uint64)
     npos_val = np.array([1000, 51000, 500, 0, 77, 0], dtype=np.uint64)
-    packed = torch.from_numpy(np.concatenate([pack_codes(codes), np.zeros(4, np.uint32)]).view(np.int32)).cuda()
-    ix, tables = sb.build_index_device(packed.data_ptr(), g, chr_start, npos_key, npos_val, interval=64, device=0,
+    host = np.concatenate([pack_codes(codes), np.zeros(4, np.uint32)])
+    d_fwd = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_fwd), host.nbytes) == 0
+    assert hip.hipMemcpy(d_fwd, host.ctypes.data, host.nbytes, 1) == 0
+    ix, tables = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, interval=64, device=0,
                                        want_index=True, want_tables=True)
+    hip.hipFree(d_fwd)
     T = tables.contents
     L_ = oracle.lib()
     c4 = (C.c_uint64 * 4)(*T.c_function4)
