@@ -177,7 +177,9 @@ def main():
 
     # index: suffix order + tables on the GPU, straight into the HBM layout; rank 0 also exports the
     # reference-format tables for the CPU baseline leg
-    want_tables = (rank == 0 and not args.no_cpu)
+    # the CPU baseline and the oracle spot check run on rank 0 of a single-GPU run only
+    run_cpu = (world == 1 and not args.no_cpu)
+    want_tables = run_cpu
     t0 = time.time()
     ix, tables = sbwt_amd.build_index_device(packed_genome.data_ptr(), g, chr_start, npos_key, npos_val, interval=64,
                                              device=local, want_index=True, want_tables=want_tables)
@@ -256,7 +258,7 @@ def main():
 
     cpu = None
     parity = None
-    if not args.no_cpu:
+    if run_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         T = tables.contents

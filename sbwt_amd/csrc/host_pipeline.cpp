@@ -8,6 +8,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -101,6 +105,100 @@ static void format_range(const sbwt_index* ix, const Record* recs, const sbwt_re
 
 using namespace sbwt;
 
+namespace sbwt {
+
+// Newline census of the file in 1 MiB chunks: upstream's reader consumes the file four lines at a time from its
+// start (fastq_reader_impl.hpp:81-98), so record k begins right after newline 4k; the census lets every host
+// thread find the first record of its share without reading what comes before.
+struct LineIndex {
+  static constexpr uint64_t kChunk = 1ull << 20;
+  const char* base = nullptr;
+  uint64_t size = 0;
+  std::vector<uint64_t> before;  // newlines before each chunk; last entry = total
+  void build(const char* p, uint64_t n, int n_threads) {
+    base = p;
+    size = n;
+    const uint64_t nc = (n + kChunk - 1) / kChunk;
+    before.assign(nc + 1, 0);
+    auto work = [&](int t) {
+      for (uint64_t c = (uint64_t)t; c < nc; c += (uint64_t)n_threads) {
+        const char* a = p + c * kChunk;
+        const char* e = p + std::min(n, (c + 1) * kChunk);
+        uint64_t cnt = 0;
+        for (const char* q = a; q < e; ++q) cnt += *q == '\n';
+        before[c + 1] = cnt;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (uint64_t c = 0; c < nc; ++c) before[c + 1] += before[c];
+  }
+  uint64_t total_lines() const { return before.empty() ? 0 : before.back(); }
+  // byte offset right after newline number `k` (k >= 1), or 0 for k == 0
+  const char* after_newline(uint64_t k) const {
+    if (k == 0) return base;
+    // chunk holding newline k: before[c] < k <= before[c + 1]
+    uint64_t c = (uint64_t)(std::lower_bound(before.begin(), before.end(), k) - before.begin()) - 1;
+    uint64_t seen = before[c];
+    const char* q = base + c * kChunk;
+    const char* e = base + size;
+    for (; q < e; ++q)
+      if (*q == '\n' && ++seen == k) return q + 1;
+    return e;
+  }
+};
+
+// SAM text leaves through one writer thread, in order, while the next batch is parsed and mapped
+class AsyncWriter {
+ public:
+  explicit AsyncWriter(FILE* f) : f_(f), th_([this] { run(); }) {}
+  ~AsyncWriter() { finish(); }
+  void push(std::vector<std::string>&& bufs) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [this] { return q_.size() < 2; });  // at most two batches of text in flight
+    q_.push_back(std::move(bufs));
+    cv_.notify_all();
+  }
+  bool finish() {
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      if (done_) return ok_;
+      done_ = true;
+      cv_.notify_all();
+    }
+    th_.join();
+    return ok_;
+  }
+
+ private:
+  void run() {
+    for (;;) {
+      std::vector<std::string> bufs;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !q_.empty() || done_; });
+        if (q_.empty()) return;
+        bufs = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+      }
+      for (auto& b : bufs)
+        if (!b.empty() && fwrite(b.data(), 1, b.size(), f_) != b.size()) ok_ = false;
+    }
+  }
+  FILE* f_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::vector<std::string>> q_;
+  bool done_ = false;
+  bool ok_ = true;
+  std::thread th_;
+};
+
+}  // namespace sbwt
+
 extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, const char* sam_path, int limit,
                               int strand, int n_threads, uint64_t stats[5]) {
   if (!ix || !fastq_path || !sam_path) return SBWT_ERR_ARG;
@@ -127,96 +225,111 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
   sbwt_ctx* ctx = nullptr;
   int rc = sbwt_ctx_create(ix, kBatch, &ctx);
   const char* p = fq.data() ? reinterpret_cast<const char*>(fq.data()) : nullptr;
-  const char* end = p ? p + fq.size() : nullptr;
+  LineIndex lines;
+  if (p) lines.build(p, fq.size(), n_threads);
+  // a record counts only when all four of its lines are newline-terminated (fastq_reader_impl.hpp:94-98)
+  const uint64_t n_records = lines.total_lines() / 4;
   std::vector<Record> recs;
   std::vector<uint32_t> packed, lens;
   std::vector<sbwt_read_result> res;
   std::vector<sbwt_hit> hits;
-  std::vector<std::string> bufs((size_t)n_threads);
-  uint64_t read_base = 0;
-  while (rc == SBWT_OK && p && p < end) {
-    recs.clear();
-    Record r;
-    uint32_t max_len = 0;
-    while (recs.size() < kBatch && next_record(p, end, r)) {
-      recs.push_back(r);
-      if (r.seq.n > max_len) max_len = r.seq.n;
-    }
-    if (recs.empty()) break;
-    const bool last = recs.size() < kBatch;
-    const uint64_t nr = recs.size();
-    const uint32_t wpr = sbwt_words_per_read(max_len);
-    packed.resize(nr * wpr);
-    lens.resize(nr);
-    res.resize(nr);
-    // pack on n_threads; the earliest offending read wins, as the upstream serial loop would hit it first
-    std::vector<uint64_t> bad_at((size_t)n_threads, ~0ull);
-    std::vector<int> bad_rc((size_t)n_threads, 0);
-    auto pack_work = [&](int t) {
-      const uint64_t a = nr * (uint64_t)t / (uint64_t)n_threads, b = nr * (uint64_t)(t + 1) / (uint64_t)n_threads;
-      for (uint64_t k = a; k < b; ++k) {
-        const int s = pack_read(recs[k].seq.p, recs[k].seq.n, wpr, &packed[k * wpr]);
-        lens[k] = recs[k].seq.n;
-        if (s != SBWT_OK && bad_at[(size_t)t] == ~0ull) { bad_at[(size_t)t] = k; bad_rc[(size_t)t] = s; }
+  bool write_ok = true;
+  {
+    AsyncWriter writer(out);
+    for (uint64_t r0 = 0; rc == SBWT_OK && r0 < n_records; r0 += kBatch) {
+      const uint64_t nr = std::min(kBatch, n_records - r0);
+      recs.resize(nr);
+      // parse: every thread finds the first record of its share through the census and reads on from there
+      std::vector<uint32_t> max_len((size_t)n_threads, 0);
+      auto parse_work = [&](int t) {
+        const uint64_t a = nr * (uint64_t)t / (uint64_t)n_threads, b = nr * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        if (a == b) return;
+        const char* q = lines.after_newline(4 * (r0 + a));
+        const char* end = p + fq.size();
+        uint32_t mx = 0;
+        for (uint64_t k = a; k < b; ++k) {
+          next_record(q, end, recs[k]);  // cannot fail: the census counted its four newlines
+          if (recs[k].seq.n > mx) mx = recs[k].seq.n;
+        }
+        max_len[(size_t)t] = mx;
+      };
+      {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(parse_work, t);
+        parse_work(0);
+        for (auto& x : th) x.join();
       }
-    };
-    {
-      std::vector<std::thread> th;
-      for (int t = 1; t < n_threads; ++t) th.emplace_back(pack_work, t);
-      pack_work(0);
-      for (auto& x : th) x.join();
-    }
-    uint64_t n_ok = nr;
-    int bad = 0;
-    for (int t = 0; t < n_threads; ++t)
-      if (bad_at[(size_t)t] != ~0ull) { n_ok = bad_at[(size_t)t]; bad = bad_rc[(size_t)t]; break; }
-    // upstream processes (and prints) every read before the offending one, then aborts
-    uint64_t n_hits = 0;
-    if (n_ok) {
-      if (hits.size() < n_ok * 2) hits.resize(n_ok * 2);
-      rc = sbwt_map_batch(ctx, packed.data(), lens.data(), n_ok, wpr, limit, strand, res.data(), hits.data(),
-                          hits.size(), &n_hits);
-      if (rc == SBWT_ERR_CAPACITY) {
-        hits.resize(n_hits + 16);
+      uint32_t longest = 0;
+      for (uint32_t v : max_len) longest = std::max(longest, v);
+      const uint32_t wpr = sbwt_words_per_read(longest);
+      packed.resize(nr * wpr);
+      lens.resize(nr);
+      res.resize(nr);
+      // pack on n_threads; the earliest offending read wins, as the upstream serial loop would hit it first
+      std::vector<uint64_t> bad_at((size_t)n_threads, ~0ull);
+      std::vector<int> bad_rc((size_t)n_threads, 0);
+      auto pack_work = [&](int t) {
+        const uint64_t a = nr * (uint64_t)t / (uint64_t)n_threads, b = nr * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        for (uint64_t k = a; k < b; ++k) {
+          const int s = pack_read(recs[k].seq.p, recs[k].seq.n, wpr, &packed[k * wpr]);
+          lens[k] = recs[k].seq.n;
+          if (s != SBWT_OK && bad_at[(size_t)t] == ~0ull) { bad_at[(size_t)t] = k; bad_rc[(size_t)t] = s; }
+        }
+      };
+      {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(pack_work, t);
+        pack_work(0);
+        for (auto& x : th) x.join();
+      }
+      uint64_t n_ok = nr;
+      int bad = 0;
+      for (int t = 0; t < n_threads; ++t)
+        if (bad_at[(size_t)t] != ~0ull) { n_ok = bad_at[(size_t)t]; bad = bad_rc[(size_t)t]; break; }
+      // upstream processes (and prints) every read before the offending one, then aborts
+      uint64_t n_hits = 0;
+      if (n_ok) {
+        if (hits.size() < n_ok * 2) hits.resize(n_ok * 2);
         rc = sbwt_map_batch(ctx, packed.data(), lens.data(), n_ok, wpr, limit, strand, res.data(), hits.data(),
                             hits.size(), &n_hits);
-      }
-      if (rc != SBWT_OK) break;
-      auto fmt_work = [&](int t) {
-        const uint64_t a = n_ok * (uint64_t)t / (uint64_t)n_threads, b = n_ok * (uint64_t)(t + 1) / (uint64_t)n_threads;
-        bufs[(size_t)t].clear();
-        format_range(ix, recs.data(), res.data(), hits.data(), a, b, bufs[(size_t)t]);
-      };
-      std::vector<std::thread> th;
-      for (int t = 1; t < n_threads; ++t) th.emplace_back(fmt_work, t);
-      fmt_work(0);
-      for (auto& x : th) x.join();
-      for (int t = 0; t < n_threads; ++t)
-        if (!bufs[(size_t)t].empty() && fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), out) != bufs[(size_t)t].size()) {
-          set_error("write error on SAM output");
-          rc = SBWT_ERR_IO;
+        if (rc == SBWT_ERR_CAPACITY) {
+          hits.resize(n_hits + 16);
+          rc = sbwt_map_batch(ctx, packed.data(), lens.data(), n_ok, wpr, limit, strand, res.data(), hits.data(),
+                              hits.size(), &n_hits);
         }
-      for (uint64_t k = 0; k < n_ok; ++k) {  // searcher.hpp:353-370
-        const int32_t nh = res[k].nh;
-        st[0]++;
-        st[4] += (uint64_t)(nh > 0 ? nh : 0);
-        if (nh == 1) { st[1]++; st[2]++; } else if (nh > 1) { st[1]++; st[3]++; }
+        if (rc != SBWT_OK) break;
+        std::vector<std::string> bufs((size_t)n_threads);
+        auto fmt_work = [&](int t) {
+          const uint64_t a = n_ok * (uint64_t)t / (uint64_t)n_threads, b = n_ok * (uint64_t)(t + 1) / (uint64_t)n_threads;
+          format_range(ix, recs.data(), res.data(), hits.data(), a, b, bufs[(size_t)t]);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(fmt_work, t);
+        fmt_work(0);
+        for (auto& x : th) x.join();
+        writer.push(std::move(bufs));
+        for (uint64_t k = 0; k < n_ok; ++k) {  // searcher.hpp:353-370
+          const int32_t nh = res[k].nh;
+          st[0]++;
+          st[4] += (uint64_t)(nh > 0 ? nh : 0);
+          if (nh == 1) { st[1]++; st[2]++; } else if (nh > 1) { st[1]++; st[3]++; }
+        }
+      }
+      if (bad) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "read %llu: %s; upstream sbwt aborts here (searcher.hpp:%d)",
+                 (unsigned long long)(r0 + n_ok),
+                 bad == SBWT_ERR_ILLEGAL_CHAR ? "illegal char (base outside ACGT)" : "shorter than 12 bases",
+                 bad == SBWT_ERR_ILLEGAL_CHAR ? 399 : 404);
+        set_error(msg);
+        rc = bad;
+        break;
       }
     }
-    if (bad) {
-      char msg[200];
-      snprintf(msg, sizeof msg, "read %llu: %s; upstream sbwt aborts here (searcher.hpp:%d)",
-               (unsigned long long)(read_base + n_ok),
-               bad == SBWT_ERR_ILLEGAL_CHAR ? "illegal char (base outside ACGT)" : "shorter than 12 bases",
-               bad == SBWT_ERR_ILLEGAL_CHAR ? 399 : 404);
-      set_error(msg);
-      rc = bad;
-      break;
-    }
-    read_base += nr;
-    if (last) break;
+    write_ok = writer.finish();
   }
   if (ctx) sbwt_ctx_free(ctx);
+  if (!write_ok && rc == SBWT_OK) { set_error("write error on SAM output"); rc = SBWT_ERR_IO; }
   if (to_stdout) fflush(out); else if (fclose(out) != 0 && rc == SBWT_OK) { set_error("write error on SAM output"); rc = SBWT_ERR_IO; }
   if (stats) memcpy(stats, st, sizeof st);
   return rc;
