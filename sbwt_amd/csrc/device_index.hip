@@ -409,7 +409,14 @@ __global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, 
     alive = step_two_bases(ix, ((uint32_t)(v >> (2 * t)) & 15u) ^ 15u, lo, hi);
   uint64_t width = hi > lo ? hi - lo : 0;
   if (width >= kKmerWide) { width = kKmerWide; lo = 0; }
-  tab[v] = lo | (width << kPosBits);
+  uint64_t entry = lo | (width << kPosBits);
+  if (width == 1) {
+    const uint64_t e = ix.sa_full[lo];
+    const uint64_t run = e >> kPosBits;
+    if (e != kNoPosition && run >= 1)
+      entry = kKmerLocated | (e & kPosMask) | ((run < kKmerRunMax ? run : kKmerRunMax) << kPosBits);
+  }
+  tab[v] = entry;
 }
 
 // ---------------------------------------------------------------------------------------------------

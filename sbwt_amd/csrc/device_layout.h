@@ -43,6 +43,10 @@ constexpr uint64_t kNoPosition = ~0ull;  // sa_full sentinel: the upstream uniqu
 // positions p, p-1, ..., p-run+1 whose rows are LF-consistent (see device_index.hip, k_verify_rows), i.e. how far
 // a size-1 interval can be carried by text comparison instead of rank queries.
 constexpr uint64_t kKmerWide = (1ull << 24) - 1;
+// kmer_tab entry of a prefix whose interval is ONE row that sa_full locates: bit 63, text position (low 40 bits),
+// run (23 bits, saturating) -- the search goes straight to the text comparison, without the sa_full access
+constexpr uint64_t kKmerLocated = 1ull << 63;
+constexpr uint64_t kKmerRunMax = (1ull << 23) - 1;
 constexpr int kPosBits = 40;
 constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
 constexpr uint64_t kRunMax = (1ull << (64 - kPosBits)) - 1;
@@ -66,7 +70,7 @@ struct DeviceIndex {
   const uint64_t* sa_full;  // memoised unique-hit locate: result of the upstream walk started at i (+ run, see above)
   const uint64_t* row_tab;  // inverse of sa_full: row whose walk reports text position p (n entries, ~0 = none)
   // memoised search prefix: entry v = interval after init_exact_match + exec_exact_match over the first kmer_order
-  // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised)
+  // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised; kKmerLocated form below)
   const uint64_t* kmer_tab; uint32_t kmer_order;  // kmer_order = 12: no table
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row_tab[n-1-x]]
   // push_position tables (searcher.hpp:504-539)

@@ -3,13 +3,13 @@
 // Upstream per-read path (searcher.hpp:386-539): reverse-complement the read, 12-mer table lookup
 // (init_exact_match :83-96), backward search (exec_exact_match :102-105, two rank queries per base),
 // suppression test (:415), locate (level-0 scan :424-443 + find_possible :460-503), push_position
-// filters (:504-539).  Here:
-//   k_search : one lane per read.  One 128-byte Block2 access advances BOTH ends of the SA interval by TWO
-//              bases.  As soon as the interval is a single row, the rest of the read is compared with the
-//              text the tables imply (textrc) and the final row comes from row_tab -- the same arithmetic
-//              as the remaining rank queries wherever the tables are LF-consistent (sa_full's run field),
-//              rank queries elsewhere.  Unique hits are filtered in place; multi-hit reads are queued.
-//   k_multi  : the upstream depth-first locate, statement for statement, for the queued reads.
+// filters (:504-539).  Here, per batch:
+//   k_search_sm  (search_machine.h): search, suppression, locate and filters of reads with at most one hit;
+//                multi-hit reads are queued with their hit slots reserved.
+//   k_multi_sort (multi_locate.h): locate of the queued reads by gather + sort in upstream emission order.
+//   k_multi      (below): the upstream depth-first locate, statement for statement, for the reads
+//                k_multi_sort cannot take.
+// This file holds k_multi, the sbwt_ctx object and the batch entry points of the C ABI.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +22,7 @@
 #include "index_impl.hpp"
 #include "rank_device.h"
 #include "search_machine.h"
+#include "multi_locate.h"
 
 namespace sbwt {
 
@@ -52,38 +53,6 @@ struct Frame {  // one activation of find_possible
   uint64_t pf, pe;
   uint32_t next_c, pad;
 };
-
-constexpr uint32_t kFlagInvalid = 0x80000000u;  // read shorter than 12 or longer than its record (never from sbwt_pack_reads)
-
-// searcher.hpp:504-539 for one lane.  chr / npos are the sorted key arrays (global memory or the workgroup's LDS
-// copy).  The upstream test "first and last base fall into the same chromosome / the same N-free segment"
-// (upper_bound - 1 of both ends, :519-533) is: no key lies in (position, position + L - 1].
-__device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos,
-                                                   uint64_t position, uint32_t L, int strand, sbwt_hit* out) {
-  bool is_rc = false;
-  if (position >= ix.real_size) {
-    is_rc = true;
-    position = ix.real_size * 2 - position - L;
-  }
-  if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
-  const uint64_t last = position + L - 1;
-  const uint32_t c1 = upper_bound_minus1(chr, ix.n_chr, position);
-  if (c1 + 1 < ix.n_chr && chr[c1 + 1] <= last) return false;
-  const uint32_t n1 = upper_bound_minus1(npos, ix.n_npos, position);
-  if (n1 + 1 < ix.n_npos && npos[n1 + 1] <= last) return false;
-  out->pos0 = position - chr[c1] + ix.npos_val[n1];
-  out->chr_id = c1;
-  out->is_rc = is_rc ? 1u : 0u;
-  return true;
-}
-__device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
-                                                   sbwt_hit* out) {
-  return push_position_keys(ix, ix.chr_start, ix.npos_key, position, L, strand, out);
-}
-
-}  // namespace sbwt
-#include "multi_locate.h"
-namespace sbwt {
 
 // ---- multi-hit locate: the upstream DFS, one lane per queued read -----------------------------
 struct MultiState {

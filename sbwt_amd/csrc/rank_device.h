@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/sbwt_amd.h"
 #include "device_layout.h"
 
 namespace sbwt {
@@ -101,5 +102,35 @@ __device__ __forceinline__ uint32_t upper_bound_minus1(const uint64_t* __restric
   }
   return l - 1;
 }
+
+// searcher.hpp:504-539 for one lane.  chr / npos_key / npos_val are the sorted tables (global memory or a
+// workgroup's LDS copy).  The upstream test "first and last base fall into the same chromosome / the same N-free
+// segment" (upper_bound - 1 of both ends, :519-533) is: no key lies in (position, position + L - 1].
+__device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos_key,
+                                                   const uint64_t* npos_val, uint64_t position, uint32_t L, int strand,
+                                                   sbwt_hit* out) {
+  bool is_rc = false;
+  if (position >= ix.real_size) {
+    is_rc = true;
+    position = ix.real_size * 2 - position - L;
+  }
+  if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
+  const uint64_t last = position + L - 1;
+  const uint32_t c1 = upper_bound_minus1(chr, ix.n_chr, position);
+  if (c1 + 1 < ix.n_chr && chr[c1 + 1] <= last) return false;
+  const uint32_t n1 = upper_bound_minus1(npos_key, ix.n_npos, position);
+  if (n1 + 1 < ix.n_npos && npos_key[n1 + 1] <= last) return false;
+  out->pos0 = position - chr[c1] + npos_val[n1];
+  out->chr_id = c1;
+  out->is_rc = is_rc ? 1u : 0u;
+  return true;
+}
+__device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
+                                                   sbwt_hit* out) {
+  return push_position_keys(ix, ix.chr_start, ix.npos_key, ix.npos_val, position, L, strand, out);
+}
+
+// results[].flags of a read shorter than 12 or longer than its record (sbwt_pack_reads never produces one)
+constexpr uint32_t kFlagInvalid = 0x80000000u;
 
 }  // namespace sbwt

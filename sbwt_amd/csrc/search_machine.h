@@ -43,28 +43,6 @@ struct SmTables {  // LDS copies (or the global originals when they do not fit)
   const uint64_t* sb_abs;
 };
 
-// push_position (searcher.hpp:504-539); tables in LDS when kLds
-__device__ __forceinline__ bool sm_push_position(const DeviceIndex& ix, const SmTables& T, uint64_t position, uint32_t L,
-                                                 int strand, sbwt_hit* out) {
-  bool is_rc = false;
-  if (position >= ix.real_size) {
-    is_rc = true;
-    position = ix.real_size * 2 - position - L;
-  }
-  if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
-  const uint64_t last = position + L - 1;
-  const uint32_t c1 = upper_bound_minus1(T.chr, ix.n_chr, position);
-  if (c1 + 1 < ix.n_chr && T.chr[c1 + 1] <= last) return false;
-  const uint32_t n1 = upper_bound_minus1(T.npos_key, ix.n_npos, position);
-  if (n1 + 1 < ix.n_npos && T.npos_key[n1 + 1] <= last) return false;
-  out->pos0 = position - T.chr[c1] + T.npos_val[n1];
-  out->chr_id = c1;
-  out->is_rc = is_rc ? 1u : 0u;
-  return true;
-}
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
@@ -95,7 +73,6 @@ struct SmArgs {
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
 constexpr uint32_t kSmMaxSuper = 16;    // superblocks of sb_abs staged in LDS (2^35 suffixes)
-constexpr uint32_t kFlagInvalidSm = 0x80000000u;
 constexpr uint32_t kSmRing = 256;       // results staged per wave (LDS, 32 B each) before they are written as whole lines
 // ring entry word 3 ("meta")
 constexpr uint32_t R_NH = 1u, R_RC = 2u, R_MULTI = 4u;  // bits 8.. = flags
@@ -114,7 +91,7 @@ __device__ __forceinline__ void sm_flush(const SmArgs& a, const uint4* ring, uin
   res.sa_hi = ((uint64_t)e0.w << 32) | e0.z;
   res.first_hit = (meta & R_NH) ? rd : ((meta & R_MULTI) ? payload : 0);
   res.nh = (meta & R_NH) ? 1 : 0;
-  res.flags = ((meta >> 8) & 3u) | (meta & kFlagInvalidSm);
+  res.flags = ((meta >> 8) & 3u) | (meta & kFlagInvalid);
   a.results[rd] = res;
   if (meta & R_NH) {  // unique hits live at the read's own index
     sbwt_hit h;
@@ -135,6 +112,7 @@ constexpr uint32_t A_HAVE_W = 1u << 20;   // the lane's NEXT read is prefetched 
 constexpr uint32_t A_HAVE_K = 1u << 21;   // ... and so is its search-prefix entry (nk)
 constexpr uint32_t A_REQ_W = 1u << 22;    // prefetch in flight this iteration
 constexpr uint32_t A_REQ_K = 1u << 23;
+constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
 
 template <bool kLds>
 __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
@@ -181,7 +159,21 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
 
   // interval after the search prefix, from a kmer_tab entry (device_layout.h)
   auto apply_prefix = [&](uint64_t e) {
-    const uint64_t width = e >> kPosBits;
+    uint64_t width = e >> kPosBits;
+    if (e & kKmerLocated) {
+      // one row, already located: straight to the text comparison when it can carry the rest of the read
+      const uint64_t pos = e & kPosMask, run = (e >> kPosBits) & kKmerRunMax;
+      const uint64_t rem = (uint64_t)L - K;
+      if (rem >= 1 && run > rem && pos >= rem) {
+        p = pos;
+        j = K;
+        lo = 0;  // the row itself is not needed: a comparison that dies reads it from row_tab
+        hi = 1;
+        aux |= A_TRIED | A_DIRECT;
+        return;
+      }
+      width = kKmerWide;  // otherwise as if not memoised
+    }
     if (width == kKmerWide) {  // not memoised (interval wider than an entry holds): the 12-mer pair, read here
       const uint32_t kmer = (~(uint32_t)w_lo) & 0xFFFFFFu;
       lo = ix.c_functions[kmer];
@@ -195,6 +187,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   // what the read needs next (searcher.hpp:406-410: one exec_exact_match per remaining base while lo < hi);
   // returns true when the search is over
   auto choose = [&]() -> bool {
+    if (aux & A_DIRECT) {
+      aux &= ~A_DIRECT;
+      st = S_CMP;
+      return false;
+    }
     if (lo >= hi || j >= L) return true;
     if ((j & 63u) == 0 && j >= 64u && !(aux & A_PIECE)) {
       aux |= A_PIECE;  // w must hold the piece j is in before anything looks at the next bases
@@ -242,7 +239,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         L = nL;
         j = kKmer;
         if (L < (uint32_t)kKmer || L > max_len) {
-          flags = kFlagInvalidSm;
+          flags = kFlagInvalid;
           lo = hi = 0;
           st = S_FIN;
         } else if (had & A_HAVE_K) {
@@ -390,7 +387,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         w_hi = u64_of(vr.z, vr.w);
         j = kKmer;
         if (L < (uint32_t)kKmer || L > max_len) {
-          flags = kFlagInvalidSm;
+          flags = kFlagInvalid;
           lo = hi = 0;
           finish = true;
         } else {
@@ -550,7 +547,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           flags |= SBWT_RF_SUPPRESSED;
         } else if (m == 1) {
           sbwt_hit h;
-          if (!(aux & A_NOPOS) && sm_push_position(ix, T, p, L, a.strand, &h)) {
+          if (!(aux & A_NOPOS) && push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h)) {
             payload = h.pos0;
             chr_id = h.chr_id;
             meta = R_NH | (h.is_rc ? R_RC : 0u);
@@ -568,7 +565,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           }
         }
         // flags: bits 0..1 and bit 31 are in use
-        meta |= ((flags & 3u) << 8) | (flags & kFlagInvalidSm);
+        meta |= ((flags & 3u) << 8) | (flags & kFlagInvalid);
         uint4* e = ring + (size_t)((r - range_begin) & (kSmRing - 1)) * 2;
         e[0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
         e[1] = make_uint4((uint32_t)payload, (uint32_t)(payload >> 32), chr_id, meta);
