@@ -152,6 +152,7 @@ struct sbwt_ctx {
   Counters* h_ctr = nullptr;  // pinned
   uint32_t* d_queue = nullptr;
   uint32_t* d_dfs_queue = nullptr;
+  WaveInfo* d_wave_info = nullptr;
   Frame* d_stacks = nullptr;
   uint32_t multi_lanes = 0;
   uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // resident workgroups of k_search_sm
@@ -201,12 +202,14 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes + ring_bytes);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, ring_bytes);
     int sort_per_cu = 0;
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort, 256, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, 0);
     c->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
     if (e == hipSuccess) {
       c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
       c->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
     }
+    if (e == hipSuccess)
+      e = hipMalloc(&c->d_wave_info, (size_t)std::max(c->grid_sm_lds, c->grid_sm_glb) * 4 * sizeof(WaveInfo));
   }
   if (e != hipSuccess) {
     sbwt_ctx_free(c);
@@ -224,6 +227,7 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   if (c->h_ctr) hipHostFree(c->h_ctr);
   hipFree(c->d_queue);
   hipFree(c->d_dfs_queue);
+  hipFree(c->d_wave_info);
   hipFree(c->d_stacks);
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits);
   for (int k = 0; k < 3; ++k)
@@ -287,6 +291,8 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
   const DeviceIndex& d = c->ix->d;
+  uint32_t n_waves = 0;
+  uint64_t chunk = 0;
   {
     SmArgs sa;
     sa.packed = d_packed;
@@ -298,10 +304,8 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     sa.results = d_results;
     sa.hits = d_hits;
     sa.hits_cap = hits_cap;
-    sa.multi_slots = &c->d_ctr->hit_count;
-    sa.multi_count = &c->d_ctr->multi_count;
-    sa.overflow = &c->d_ctr->overflow;
     sa.multi_queue = c->d_queue;
+    sa.wave_info = c->d_wave_info;
     sa.index_accesses = &c->d_ctr->index_accesses;
     const bool lds = c->sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
@@ -309,20 +313,31 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     if (lds) k_search_sm<true><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
     else k_search_sm<false><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
     SBWT_LAUNCHED();
+    n_waves = grid * 4;
+    chunk = ((n_reads + n_waves - 1) / n_waves + 63) & ~63ull;  // as k_search_sm splits the batch
   }
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
   {
     // multi-hit reads: gather + sort where the tables allow it, the upstream depth-first walk for the rest
+    k_multi_plan<<<1, 1024, 0, c->stream>>>(c->d_wave_info, n_waves, n_reads, hits_cap, &c->d_ctr->hit_count,
+                                            &c->d_ctr->multi_count, &c->d_ctr->overflow);
+    SBWT_LAUNCHED();
     MultiSortArgs ms;
     ms.lens = d_lens;
     ms.strand = strand;
     ms.results = d_results;
     ms.hits = d_hits;
+    ms.n_reads = n_reads;
     ms.queue = c->d_queue;
+    ms.wave_info = c->d_wave_info;
+    ms.n_waves = n_waves;
+    ms.chunk = chunk;
     ms.queue_count = &c->d_ctr->multi_count;
+    ms.overflow = &c->d_ctr->overflow;
     ms.dfs_queue = c->d_dfs_queue;
     ms.dfs_count = &c->d_ctr->dfs_count;
-    k_multi_sort<<<c->grid_sort, 256, 0, c->stream>>>(d, ms);
+    k_multi_sort<64><<<c->grid_sort, 256, 0, c->stream>>>(d, ms);
+    k_multi_sort<256><<<c->grid_sort, 256, 0, c->stream>>>(d, ms);
     SBWT_LAUNCHED();
     k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(d, a, c->d_stacks, c->multi_lanes, c->d_dfs_queue,
                                                          &c->d_ctr->dfs_count);

@@ -54,6 +54,12 @@ __device__ __forceinline__ void sm_funnel128(uint64_t q0, uint64_t q1, uint64_t 
   c1 = sh ? ((q1 >> sh) | (q2 << (64 - sh))) : q1;
 }
 
+struct WaveInfo {
+  uint64_t slots;      // hit slots the wave's multi-hit reads need (k_search_sm) -> exclusive prefix over waves (k_multi_plan)
+  uint32_t count;      // multi-hit reads of the wave
+  uint32_t queue_base; // exclusive prefix of count over waves (k_multi_plan)
+};
+
 struct SmArgs {
   const uint32_t* packed;
   const uint32_t* lens;
@@ -64,10 +70,11 @@ struct SmArgs {
   sbwt_read_result* results;
   sbwt_hit* hits;
   uint64_t hits_cap;
-  unsigned long long* multi_slots;  // slots handed out after the first n_reads (multi-hit reads)
-  unsigned long long* multi_count;
-  unsigned int* overflow;
+  // multi-hit reads: no atomics.  Wave w keeps the queue entries of its own range of reads in
+  // multi_queue[range_begin(w) ..) and numbers the hit slots it needs from 0; its totals go to wave_info[w], and
+  // k_multi_plan turns them into global offsets for the locate kernels.
   uint32_t* multi_queue;
+  struct WaveInfo* wave_info;
   unsigned long long* index_accesses;  // tally of random index accesses (for the roofline accounting)
 };
 
@@ -154,6 +161,8 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   bool reserve = false;
   uint64_t flushed = range_begin;  // wave-uniform: results of reads below it are in global memory
   uint32_t tally = 0;              // random index accesses this lane needed (128-byte lines)
+  uint64_t wave_slots = 0;  // wave-uniform: hit slots handed to the multi-hit reads of this wave so far
+  uint32_t wave_multi = 0;  // wave-uniform: how many such reads
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0;
   uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0, nw_lo = 0, nw_hi = 0, nk = 0;
 
@@ -534,47 +543,66 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         break;
     }
 
-    if (finish) {
-      // suppression (searcher.hpp:415), locate of a size-1 interval, filters, output
-      const uint64_t m = hi > lo ? hi - lo : 0;
-      if (m == 1 && m <= a.limit && !(aux & A_LOCATED)) {
-        st = S_LOCATE;
-      } else {
-        uint32_t meta = 0;
-        uint64_t payload = 0;  // unique hit: position in its chromosome; multi-hit read: first reserved slot
-        uint32_t chr_id = 0;
-        if (m > a.limit) {
-          flags |= SBWT_RF_SUPPRESSED;
-        } else if (m == 1) {
-          sbwt_hit h;
-          if (!(aux & A_NOPOS) && push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h)) {
-            payload = h.pos0;
-            chr_id = h.chr_id;
-            meta = R_NH | (h.is_rc ? R_RC : 0u);
-          }
-        } else if (m > 1) {
-          // multi-hit read: reserve m slots behind the first n_reads and hand the read to k_multi
-          const uint64_t slot = a.n_reads + atomicAdd(a.multi_slots, (unsigned long long)m);
-          if (slot + m <= a.hits_cap) {
-            payload = slot;
-            meta = R_MULTI;
-            const unsigned long long q = atomicAdd(a.multi_count, 1ull);
-            a.multi_queue[q] = (uint32_t)r;
-          } else {
-            atomicOr(a.overflow, 1u);
-          }
-        }
-        // flags: bits 0..1 and bit 31 are in use
-        meta |= ((flags & 3u) << 8) | (flags & kFlagInvalid);
-        uint4* e = ring + (size_t)((r - range_begin) & (kSmRing - 1)) * 2;
-        e[0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-        e[1] = make_uint4((uint32_t)payload, (uint32_t)(payload >> 32), chr_id, meta);
-
-        // the lane's next read is the one it reserved; it starts at the top of the loop
-        r = rn;
-        st = r < range_end ? S_START : S_IDLE;
-      }
+    // ---- a finished search: suppression (searcher.hpp:415), locate of a size-1 interval, filters, output
+    const uint64_t m = finish && hi > lo ? hi - lo : 0;
+    if (finish && m == 1 && m <= a.limit && !(aux & A_LOCATED)) {
+      st = S_LOCATE;
+      finish = false;
     }
+    // multi-hit reads take hit slots (numbered within the wave; k_multi_plan makes them global) and a queue entry
+    // in the wave's own stretch of the queue
+    const uint64_t want = (finish && m > 1 && m <= a.limit) ? m : 0;
+    uint64_t multi_off = 0;
+    const uint64_t mm = __ballot(want != 0);
+    if (mm) {
+      uint64_t inc = want;  // inclusive scan of `want` over the wave
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = ((uint64_t)__shfl_up((int)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+        if ((int)lane >= d) inc += up;
+      }
+      const uint64_t total = ((uint64_t)__shfl((int)(inc >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)inc, 63);
+      if (want) {
+        multi_off = wave_slots + (inc - want);
+        a.multi_queue[range_begin + wave_multi + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+      }
+      wave_slots += total;
+      wave_multi += (uint32_t)__popcll(mm);
+    }
+    if (finish) {
+      uint32_t meta = 0;
+      uint64_t payload = 0;  // unique hit: position in its chromosome; multi-hit read: first reserved slot
+      uint32_t chr_id = 0;
+      if (m > a.limit) {
+        flags |= SBWT_RF_SUPPRESSED;
+      } else if (m == 1) {
+        sbwt_hit h;
+        if (!(aux & A_NOPOS) && push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h)) {
+          payload = h.pos0;
+          chr_id = h.chr_id;
+          meta = R_NH | (h.is_rc ? R_RC : 0u);
+        }
+      } else if (want) {
+        payload = multi_off;  // first slot, wave-relative until k_multi_sort adds the wave's base
+        meta = R_MULTI;
+      }
+      // flags: bits 0..1 and bit 31 are in use
+      meta |= ((flags & 3u) << 8) | (flags & kFlagInvalid);
+      uint4* e = ring + (size_t)((r - range_begin) & (kSmRing - 1)) * 2;
+      e[0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+      e[1] = make_uint4((uint32_t)payload, (uint32_t)(payload >> 32), chr_id, meta);
+
+      // the lane's next read is the one it reserved; it starts at the top of the loop
+      r = rn;
+      st = r < range_end ? S_START : S_IDLE;
+    }
+  }
+  if (lane == 0) {
+    WaveInfo wi;
+    wi.slots = wave_slots;
+    wi.count = wave_multi;
+    wi.queue_base = 0;
+    a.wave_info[wave] = wi;
   }
   {
     uint32_t t = tally;
