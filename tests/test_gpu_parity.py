@@ -204,3 +204,51 @@ def test_corrupt_index_is_rejected(sb, golden_indexes, tmp_path):
     with pytest.raises(sb.SbwtError) as e:
         sb.Index.load(str(tmp_path / "c"))
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("interval", [16, 256])
+def test_other_sampling_intervals(sb, oracle, golden_dir, tmp_path, interval):
+    """`sbwt build -s`: interval 16 (short locate walks) and 256 (the sorted multi-hit locate hands over to the
+    depth-first kernel above 64)"""
+    prefix = str(tmp_path / "g2")
+    oracle.build_index(os.path.join(golden_dir, "g2.fa"), prefix, interval=interval)
+    ix, oix = sb.Index.load(prefix), oracle.OracleIndex.load(prefix)
+    assert ix.info().interval == interval
+    seq = genome_text(os.path.join(golden_dir, "g2.fa"))
+    rng = np.random.default_rng(interval)
+    reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
+    for L in (14, 20, 33, 50, 80):
+        for _ in range(150):
+            p = int(rng.integers(0, len(seq) - L))
+            s = seq[p:p + L]
+            if "N" in s:
+                continue
+            reads.append(s.translate(COMP)[::-1] if rng.random() < 0.5 else s)
+    ctx = sb.Context(ix, len(reads))
+    res, _ = assert_same(sb, ctx, oix, reads)
+    assert res["nh"].max() >= 3
+    st = ctx.last_stats()
+    assert st[1] >= 2 and (st[3] >= 2 if interval > 64 else st[3] == 0)   # multi-hit reads; depth-first only above 64
+    ctx.close(); ix.close(); oix.close()
+
+
+def test_hits_layout_and_capacity_retry(sb, loaded, golden_dir):
+    """unique hits live at their read's index, multi-hit lists behind the first n_reads slots; a buffer that holds
+    the reads but not the lists fails with the size a retry needs"""
+    ix, oix = loaded["g2"]
+    reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
+    packed, lens = sb.pack_reads(reads)
+    n = len(reads)
+    ctx = sb.Context(ix, n)
+    with pytest.raises(sb.SbwtError) as e:
+        ctx.map_batch(packed, lens, hits_cap=n)          # room for the unique hits only
+    assert e.value.code == -7 and "%d slots needed" % (n + 6) in str(e.value)
+    res, hits = ctx.map_batch(packed, lens, hits_cap=n + 6)
+    lo, hi, nh, first, ohits = oix.map_batch(reads)
+    np.testing.assert_array_equal(res["nh"], nh)
+    uniq = np.nonzero(nh == 1)[0]
+    np.testing.assert_array_equal(res["first_hit"][uniq], uniq)
+    multi = np.nonzero(nh > 1)[0]
+    assert len(multi) == 2 and (res["first_hit"][multi] >= n).all()
+    assert ctx.last_stats()[2] == n + 6 and ctx.last_stats()[0] > 0
+    ctx.close()
