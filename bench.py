@@ -92,7 +92,7 @@ def plant_repeats(torch, dev, codes, g, seed, n_families=2000, max_copies=5000):
     return slots
 
 
-def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=None):
+def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=None, mutate=0.0):
     """n_reads error-free reads, strand uniform -> packed int32 [n_reads, wpr], lens int32.  Length L, or uniform
     in min_len..L; with `slots`, half of the reads start inside a planted repeat"""
     gen = torch.Generator(device=dev)
@@ -113,6 +113,13 @@ def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=
         bases = codes[(pos[:, None] + ar[None, :])].to(torch.int32)          # forward strand
         rc = 3 - bases.flip(1)
         bases = torch.where(rev[:, None], rc, bases)
+        if mutate > 0.0:
+            # one substitution in a fraction of the reads (they die somewhere along the search)
+            hit = torch.rand(b - a, device=dev, generator=gen) < mutate
+            where = torch.randint(0, L, (b - a,), device=dev, generator=gen)
+            delta = torch.randint(1, 4, (b - a,), device=dev, generator=gen, dtype=torch.int32)
+            rows = torch.nonzero(hit).squeeze(1)
+            bases[rows, where[rows]] = (bases[rows, where[rows]] + delta[rows]) & 3
         buf = torch.zeros((b - a, wpr * 16), dtype=torch.int32, device=dev)
         buf[:, :L] = bases
         if min_len is not None:
@@ -146,6 +153,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--min-len", type=int, default=None, help="reads of length min-len..read-len (config 5)")
+    ap.add_argument("--mutate", type=float, default=0.0, help="fraction of reads with one substitution")
     ap.add_argument("--repeats", action="store_true", help="plant a repeat family, half of the reads inside it (config 5)")
     args = ap.parse_args()
 
@@ -190,7 +198,7 @@ def main():
     wpr = sbwt_amd.words_per_read(L)
     n_reads = args.reads
     t0 = time.time()
-    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots)
+    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots, mutate=args.mutate)
     del codes
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
@@ -308,10 +316,11 @@ def main():
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s), %d x %s exact reads per GPU, "
+        "config": {"workload": "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s), %d x %s reads per GPU, "
                                "both strands, -m 1000 -s 2, inputs resident in HBM"
                                % (g / 1e9, ", planted repeat family" if args.repeats else "", n_reads,
-                                  "%d-bp" % L if args.min_len is None else "%d..%d-nt" % (args.min_len, L)),
+                                  ("%d-bp" % L if args.min_len is None else "%d..%d-nt" % (args.min_len, L))
+                                  + (" (%.0f%% with one substitution)" % (100 * args.mutate) if args.mutate else " exact")),
                    "index_suffixes": int(info.n), "index_hbm_GB": round(info.device_bytes / 1e9, 2),
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu,
