@@ -182,22 +182,17 @@ __global__ __launch_bounds__(256) void k_apply1(Block1* __restrict__ blocks, uin
 // sa_full[i] = what the upstream locate reports for the interval [i, i+1): level-0 test
 // (searcher.hpp:424-443) then find_possible (searcher.hpp:460-503) on a size-1 interval, i.e. follow LF
 // until a sampled position; kNoPosition if depth `interval` or the '$' row is reached first.
-__global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __restrict__ sa_full) {
-  const uint64_t i = global_thread();
-  if (i >= ix.n) return;
-  uint64_t cur = i, t = 0, res = kNoPosition;
+__device__ __forceinline__ uint64_t upstream_walk(const DeviceIndex& ix, uint64_t i) {
+  uint64_t cur = i, t = 0;
   for (;;) {
     const Block1* b = ix.blocks1 + (cur >> 6);
     const uint4 pl = *reinterpret_cast<const uint4*>(&b->plane_lo);
     const uint4 sm = *reinterpret_cast<const uint4*>(&b->sampled);
     const uint32_t o = (uint32_t)(cur & 63);
     const uint64_t sampled = ((uint64_t)sm.y << 32) | sm.x, base = ((uint64_t)sm.w << 32) | sm.z;
-    if ((sampled >> o) & 1ull) {
-      res = ix.loc_vals[base + (uint64_t)__popcll(sampled & below(o))] + t;
-      break;
-    }
-    if (t + 1 >= ix.interval) break;      // find_possible: len >= interval
-    if (cur == ix.first_location) break;  // '$' row: every child interval is empty
+    if ((sampled >> o) & 1ull) return ix.loc_vals[base + (uint64_t)__popcll(sampled & below(o))] + t;
+    if (t + 1 >= ix.interval) return kNoPosition;      // find_possible: len >= interval
+    if (cur == ix.first_location) return kNoPosition;  // '$' row: every child interval is empty
     const uint64_t plo = ((uint64_t)pl.y << 32) | pl.x, phi = ((uint64_t)pl.w << 32) | pl.z;
     const uint32_t c = (uint32_t)((plo >> o) & 1ull) | ((uint32_t)((phi >> o) & 1ull) << 1);
     uint64_t r = b->cnt[c] + (uint64_t)__popcll(match1(plo, phi, c) & below(o));
@@ -205,7 +200,78 @@ __global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __res
     cur = r;
     ++t;
   }
-  sa_full[i] = res;
+}
+
+// the definition, row by row: about interval / 2 dependent gathers per row
+__global__ __launch_bounds__(256) void k_sa_full(DeviceIndex ix, uint64_t* __restrict__ sa_full) {
+  const uint64_t i = global_thread();
+  if (i >= ix.n) return;
+  sa_full[i] = upstream_walk(ix, i);
+}
+
+// The same values with about two gathers per row, for tables that are LF-consistent (every properly built index
+// whose ties beyond sort_len do not matter).  The walk of row x ends on the first sampled row below it; seen from
+// a sampled row s the rows LF(s), LF^2(s), ... are, on a consistent index, the rows whose walks end on the NEXT
+// sampled row with values loc(s) - 1, loc(s) - 2, ...  k_sa_fast assigns those, k_sa_fill walks the few rows no
+// chain reached, and k_sa_check accepts the result only if EVERY row satisfies the recurrence that defines the
+// walk (a sampled row reports its own value; any other row reports its LF row's value + 1, and is not a multiple
+// of the sampling distance, which bounds the walk below `interval` steps).  Otherwise k_sa_full runs.
+struct SaCheck {
+  unsigned long long unset;   // rows no chain reached (walked one by one)
+  unsigned long long failed;  // rows violating the recurrence
+};
+
+__global__ __launch_bounds__(256) void k_sa_fast(DeviceIndex ix, const uint64_t* __restrict__ loc, uint64_t n_loc,
+                                                 uint64_t* __restrict__ sa_full, SaCheck* chk) {
+  const uint64_t k = global_thread();
+  if (k >= n_loc) return;
+  uint64_t cur = loc[2 * k];
+  const uint64_t val = loc[2 * k + 1];
+  if (val % ix.interval != 0 || val >= ix.n) {
+    atomicAdd(&chk->failed, 1ull);
+    return;
+  }
+  sa_full[cur] = val;
+  for (uint64_t t = 1; t < ix.interval && t <= val; ++t) {
+    if (cur == ix.first_location) break;
+    const Block1* b = ix.blocks1 + (cur >> 6);
+    const uint32_t o = (uint32_t)(cur & 63);
+    const uint64_t plo = b->plane_lo, phi = b->plane_hi;
+    const uint32_t c = (uint32_t)((plo >> o) & 1ull) | ((uint32_t)((phi >> o) & 1ull) << 1);
+    uint64_t r = b->cnt[c] + (uint64_t)__popcll(match1(plo, phi, c) & below(o));
+    if (c == 0 && cur > ix.first_location) r -= 1;
+    cur = r;
+    const Block1* nb = ix.blocks1 + (cur >> 6);
+    if ((nb->sampled >> (cur & 63)) & 1ull) break;  // a sampled row answers for itself
+    sa_full[cur] = val - t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sa_fill(DeviceIndex ix, uint64_t* __restrict__ sa_full, SaCheck* chk) {
+  const uint64_t i = global_thread();
+  if (i >= ix.n) return;
+  if (sa_full[i] != kNoPosition) return;
+  atomicAdd(&chk->unset, 1ull);
+  sa_full[i] = upstream_walk(ix, i);
+}
+
+__global__ __launch_bounds__(256) void k_sa_check(DeviceIndex ix, const uint64_t* __restrict__ sa_full, SaCheck* chk) {
+  const uint64_t j = global_thread();
+  if (j >= ix.n) return;
+  const Block1* b = ix.blocks1 + (j >> 6);
+  const uint32_t o = (uint32_t)(j & 63);
+  if ((b->sampled >> o) & 1ull) return;  // k_sa_fast wrote its own value
+  const uint64_t v = sa_full[j];
+  bool ok;
+  if (j == ix.first_location) {
+    ok = v == kNoPosition;  // an unsampled '$' row reports nothing
+  } else {
+    const uint64_t plo = b->plane_lo, phi = b->plane_hi;
+    const uint32_t c = (uint32_t)((plo >> o) & 1ull) | ((uint32_t)((phi >> o) & 1ull) << 1);
+    const uint64_t nx = sa_full[lf1(ix, j, c)];
+    ok = v != kNoPosition && nx != kNoPosition && v == nx + 1 && v % ix.interval != 0;
+  }
+  if (!ok) atomicAdd(&chk->failed, 1ull);
 }
 
 // ---- text-jump tables ---------------------------------------------------------------------------------
@@ -484,8 +550,23 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     return -2;  // SBWT_ERR_FORMAT
   }
 
-  k_sa_full<<<grid_for(raw.n, 256), 256>>>(d, sa_full);
-  SBWT_LAUNCHED();
+  {
+    SaCheck* d_chk = nullptr;
+    SaCheck h_chk;
+    SBWT_HIP(hipMalloc(&d_chk, sizeof(SaCheck)));
+    SBWT_HIP(hipMemset(d_chk, 0, sizeof(SaCheck)));
+    SBWT_HIP(hipMemset(sa_full, 0xff, raw.n * sizeof(uint64_t)));
+    if (raw.n_loc) k_sa_fast<<<grid_for(raw.n_loc, 256), 256>>>(d, raw.loc, raw.n_loc, sa_full, d_chk);
+    k_sa_fill<<<grid_for(raw.n, 256), 256>>>(d, sa_full, d_chk);
+    k_sa_check<<<grid_for(raw.n, 256), 256>>>(d, sa_full, d_chk);
+    SBWT_LAUNCHED();
+    SBWT_HIP(hipMemcpy(&h_chk, d_chk, sizeof h_chk, hipMemcpyDeviceToHost));
+    hipFree(d_chk);
+    if (h_chk.failed || getenv("SBWT_SLOW_SA")) {
+      k_sa_full<<<grid_for(raw.n, 256), 256>>>(d, sa_full);
+      SBWT_LAUNCHED();
+    }
+  }
   d.sa_full = sa_full;
   if (raw.n >= (1ull << kPosBits)) {
     set_error("index has 2^40 suffixes or more");
