@@ -89,25 +89,25 @@ __global__ __launch_bounds__(256) void k_make_text(const uint32_t* __restrict__ 
   text[w] = out;
 }
 
-__global__ __launch_bounds__(256) void k_prefix_hist(Text T, uint64_t n, int D, uint32_t n_part,
+// histogram of the leading D digits over the positions [begin, end)
+__global__ __launch_bounds__(256) void k_prefix_hist(Text T, uint64_t begin, uint64_t end, int D, uint32_t n_part,
                                                      unsigned long long* hist) {
   __shared__ unsigned int h[15625];  // 5^6
   for (uint32_t k = threadIdx.x; k < n_part; k += blockDim.x) h[k] = 0;
   __syncthreads();
   // each workgroup sweeps a contiguous slab so that the global atomics stay few
   const uint64_t slab = 256ull * 64;
-  const uint64_t a = (uint64_t)blockIdx.x * slab;
-  for (uint64_t p = a + threadIdx.x; p < a + slab && p < n; p += blockDim.x) atomicAdd(&h[prefix_digits(T, p, D)], 1u);
+  const uint64_t a = begin + (uint64_t)blockIdx.x * slab;
+  for (uint64_t p = a + threadIdx.x; p < a + slab && p < end; p += blockDim.x) atomicAdd(&h[prefix_digits(T, p, D)], 1u);
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < n_part; k += blockDim.x)
     if (h[k]) atomicAdd(&hist[k], (unsigned long long)h[k]);
 }
 
-struct PrefixIs {
+struct PartitionOf {  // partition id (leading D digits, < 5^6 < 2^16) of the suffix at a position
   Text T;
   int D;
-  uint32_t v;
-  __device__ bool operator()(const uint64_t& p) const { return prefix_digits(T, p, D) == v; }
+  __device__ uint16_t operator()(const uint64_t& p) const { return (uint16_t)prefix_digits(T, p, D); }
 };
 
 __global__ __launch_bounds__(256) void k_keys(Text T, const uint64_t* __restrict__ pos, uint64_t cnt, uint64_t off,
@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256) void k_keys(Text T, const uint64_t* __restrict
   if (t < cnt) keys[t] = key5(T, pos[t] + off);
 }
 
+__global__ __launch_bounds__(256) void k_iota64(uint64_t* a, uint64_t cnt) {
+  const uint64_t t = global_thread();
+  if (t < cnt) a[t] = t;
+}
 __global__ __launch_bounds__(256) void k_iota(uint32_t* a, uint64_t cnt) {
   const uint64_t t = global_thread();
   if (t < cnt) a[t] = (uint32_t)t;
@@ -454,14 +458,39 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
   while (D < 6 && (n >> (2 * D)) > kMaxPartition / 2) ++D;
   uint32_t n_part = 1;
   for (int k = 0; k < D; ++k) n_part *= 5;
+  // Positions grouped by partition.  The text is cut into slabs of 2^30 positions (rocPRIM indexes its input with
+  // 32 bits); each slab is radix-sorted ONCE by partition id, stably, so inside a slab every partition's positions
+  // are contiguous and ascending, and a partition is the concatenation of its stretch in every slab.
+  constexpr uint64_t kSlab = 1ull << 30;
+  const uint32_t n_slab = (uint32_t)((n + kSlab - 1) / kSlab);
   DevBuf<unsigned long long> d_hist;
-  if (int rc = d_hist.alloc(n_part)) return rc;
-  SBWT_HIP(hipMemset(d_hist.p, 0, n_part * 8));
-  std::vector<unsigned long long> hist(n_part, 0);
-  if (D == 0) hist[0] = n;
+  if (int rc = d_hist.alloc((uint64_t)n_slab * n_part)) return rc;
+  SBWT_HIP(hipMemset(d_hist.p, 0, (uint64_t)n_slab * n_part * 8));
+  std::vector<unsigned long long> slab_hist((uint64_t)n_slab * n_part, 0), hist(n_part, 0);
+  DevBuf<uint64_t> pos_all;
+  if (D == 0) hist[0] = slab_hist[0] = n;
   else {
-    k_prefix_hist<<<(uint32_t)((n + 256ull * 64 - 1) / (256ull * 64)), 256>>>(T, n, D, n_part, d_hist.p);
-    SBWT_HIP(hipMemcpy(hist.data(), d_hist.p, n_part * 8, hipMemcpyDeviceToHost));
+    if (int rc = pos_all.alloc(n)) return rc;
+    DevBuf<uint16_t> part_keys;
+    if (int rc = part_keys.alloc(std::min<uint64_t>(kSlab, n))) return rc;
+    Scratch tmp;
+    unsigned bits = 1;
+    while ((1u << bits) < n_part) ++bits;
+    for (uint32_t s = 0; s < n_slab; ++s) {
+      const uint64_t c0 = (uint64_t)s * kSlab, len = std::min<uint64_t>(kSlab, n - c0);
+      k_prefix_hist<<<(uint32_t)((len + 256ull * 64 - 1) / (256ull * 64)), 256>>>(T, c0, c0 + len, D, n_part,
+                                                                                 d_hist.p + (uint64_t)s * n_part);
+      SBWT_LAUNCHED();
+      auto keys_in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(c0), PartitionOf{T, D});
+      rocprim::counting_iterator<uint64_t> vals_in(c0);
+      size_t bytes = 0;
+      SBWT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, part_keys.p, vals_in, pos_all.p + c0, (size_t)len, 0u, bits));
+      if (int rc = tmp.need(bytes)) return rc;
+      SBWT_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_in, part_keys.p, vals_in, pos_all.p + c0, (size_t)len, 0u, bits));
+    }
+    SBWT_HIP(hipMemcpy(slab_hist.data(), d_hist.p, slab_hist.size() * 8, hipMemcpyDeviceToHost));
+    for (uint32_t s = 0; s < n_slab; ++s)
+      for (uint32_t v = 0; v < n_part; ++v) hist[v] += slab_hist[(uint64_t)s * n_part + v];
   }
   uint64_t max_part = 0;
   for (auto h : hist) max_part = std::max<uint64_t>(max_part, h);
@@ -472,29 +501,23 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
   {
     PartitionSorter S;
     if (int rc = S.reserve(max_part)) return rc;
+    std::vector<uint64_t> slab_off(n_slab, 0);  // where the next partition starts inside each slab
     for (uint32_t v = 0; v < n_part; ++v) {
       const uint64_t cnt = hist[v];
-      if (cnt == 0) continue;
-      {
-        // positions of this partition, gathered in input slabs of 2^30 (rocPRIM's select indexes its input
-        // with 32 bits; a single call over > 2^32 suffixes silently returns wrong positions)
-        PrefixIs pred{T, D, v};
+      if (D == 0) {
+        k_iota64<<<blocks_for(n), 256>>>(S.pos_a.p, n);
+        SBWT_LAUNCHED();
+      } else {
         uint64_t got = 0;
-        for (uint64_t c0 = 0; c0 < n; c0 += (1ull << 30)) {
-          const uint64_t len = std::min<uint64_t>(1ull << 30, n - c0);
-          size_t bytes = 0;
-          SBWT_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint64_t>(c0), S.pos_a.p + got, S.d_count.p, (size_t)len, pred));
-          if (int rc = S.tmp.need(bytes)) return rc;
-          SBWT_HIP(rocprim::select(S.tmp.p, bytes, rocprim::counting_iterator<uint64_t>(c0), S.pos_a.p + got, S.d_count.p, (size_t)len, pred));
-          uint64_t c = 0;
-          SBWT_HIP(hipMemcpy(&c, S.d_count.p, 8, hipMemcpyDeviceToHost));
+        for (uint32_t s = 0; s < n_slab; ++s) {
+          const uint64_t c = slab_hist[(uint64_t)s * n_part + v];
+          if (c) SBWT_HIP(hipMemcpyAsync(S.pos_a.p + got, pos_all.p + (uint64_t)s * kSlab + slab_off[s], c * 8,
+                                         hipMemcpyDeviceToDevice, 0));
+          slab_off[s] += c;
           got += c;
         }
-        if (got != cnt) {
-          set_error("index builder: partition size mismatch");
-          return SBWT_ERR_HIP;
-        }
       }
+      if (cnt == 0) continue;
       if (int rc = S.run(T, cnt, sa.p + base)) return rc;
       base += cnt;
     }
@@ -513,6 +536,7 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
               h[2] == want ? "ok" : "BAD");
     }
   }
+  pos_all.release();
 
   // ---- tables ----
   RawDeviceTables& raw = R.raw;
