@@ -6,9 +6,11 @@
 // same lines with 1000-read groups in arbitrary order).
 #include <ctype.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -56,49 +58,94 @@ static bool next_record(const char*& p, const char* end, Record& r) {
   return true;
 }
 
-static inline void put_u64(std::string& s, uint64_t v) {
+// growing text buffer without zero fill; room(k) guarantees k writable bytes at end()
+struct TextBuf {
+  char* p = nullptr;
+  size_t n = 0, cap = 0;
+  TextBuf() = default;
+  TextBuf(const TextBuf&) = delete;
+  TextBuf& operator=(const TextBuf&) = delete;
+  TextBuf(TextBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+  TextBuf& operator=(TextBuf&& o) noexcept {
+    if (this != &o) { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; }
+    return *this;
+  }
+  ~TextBuf() { free(p); }
+  bool room(size_t k) {
+    if (cap - n >= k) return true;
+    size_t c = cap ? cap * 2 : (size_t)1 << 16;
+    while (c - n < k) c *= 2;
+    char* q = static_cast<char*>(realloc(p, c));
+    if (!q) return false;
+    p = q;
+    cap = c;
+    return true;
+  }
+};
+
+static inline char* put_u64(char* o, uint64_t v) {
   char t[24];
   int k = 0;
   do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v);
-  while (k) s.push_back(t[--k]);
+  while (k) *o++ = t[--k];
+  return o;
 }
 
-static void format_range(const sbwt_index* ix, const Record* recs, const sbwt_read_result* res, const sbwt_hit* hits,
-                         uint64_t r0, uint64_t r1, std::string& out) {
-  std::string rc_seq, rev_qual;
+struct RevComp {
+  char t[256];
+  RevComp() {
+    memset(t, 'A', sizeof t);  // bytes outside ACGT never reach the formatter (pack_read rejects them)
+    t[(unsigned char)'A'] = 'T'; t[(unsigned char)'C'] = 'G'; t[(unsigned char)'G'] = 'C'; t[(unsigned char)'T'] = 'A';
+  }
+};
+
+static bool format_range(const sbwt_index* ix, const Record* recs, const sbwt_read_result* res, const sbwt_hit* hits,
+                         uint64_t r0, uint64_t r1, TextBuf& out) {
+  static const RevComp rc;
+  size_t longest_chr = 0;
+  for (const auto& nm : ix->chr.names) longest_chr = std::max(longest_chr, nm.size());
+  std::vector<char> rc_seq, rev_qual;
   for (uint64_t r = r0; r < r1; ++r) {
     const int32_t nh = res[r].nh;
     if (nh <= 0) continue;
     const Record& q = recs[r];
-    const uint32_t L = q.seq.n;
-    rc_seq.resize(L);
-    for (uint32_t k = 0; k < L; ++k) {
-      const char c = q.seq.p[L - 1 - k];
-      rc_seq[k] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
-    }
-    rev_qual.assign(q.qual.p, q.qual.n);
-    for (uint32_t a = 0, b = q.qual.n; a + 1 < b; ++a, --b) std::swap(rev_qual[a], rev_qual[b - 1]);
+    const uint32_t L = q.seq.n, QL = q.qual.n;
+    bool have_rev = false;
+    const size_t line_max = (size_t)q.name.n + longest_chr + L + QL + 96;
     for (int32_t h = 0; h < nh; ++h) {
       const sbwt_hit& H = hits[res[r].first_hit + (uint64_t)h];
+      if (!H.is_rc && !have_rev) {  // searcher.hpp:551-571: SEQ reverse-complemented, QUAL reversed
+        if (rc_seq.size() < L) rc_seq.resize(L);
+        if (rev_qual.size() < QL) rev_qual.resize(QL);
+        for (uint32_t k = 0; k < L; ++k) rc_seq[k] = rc.t[(unsigned char)q.seq.p[L - 1 - k]];
+        for (uint32_t k = 0; k < QL; ++k) rev_qual[k] = q.qual.p[QL - 1 - k];
+        have_rev = true;
+      }
+      if (!out.room(line_max)) return false;
+      char* o = out.p + out.n;
       // every field, the last included, is followed by a tab (tuple_utility.hpp:54-64), then '\n'
-      if (q.name.n > 1) out.append(q.name.p + 1, q.name.n - 1);  // Fastq::getName: substr(1)
-      out.push_back('\t');
-      out.append(H.is_rc ? "0" : "16");  // searcher.hpp:551-593
-      out.push_back('\t');
-      out.append(ix->chr.names[H.chr_id]);
-      out.push_back('\t');
-      put_u64(out, H.pos0 + 1);
-      out.append("\t255\t");
-      put_u64(out, L);
-      out.append("M\t*\t0\t0\t");
-      if (H.is_rc) out.append(q.seq.p, L); else out.append(rc_seq);
-      out.push_back('\t');
-      if (H.is_rc) out.append(q.qual.p, q.qual.n); else out.append(rev_qual);
-      out.push_back('\t');
-      put_u64(out, (uint64_t)nh);
-      out.append("\t\n");
+      if (q.name.n > 1) { memcpy(o, q.name.p + 1, q.name.n - 1); o += q.name.n - 1; }  // Fastq::getName: substr(1)
+      *o++ = '\t';
+      if (H.is_rc) *o++ = '0'; else { *o++ = '1'; *o++ = '6'; }  // searcher.hpp:551-593
+      *o++ = '\t';
+      const std::string& chr = ix->chr.names[H.chr_id];
+      memcpy(o, chr.data(), chr.size()); o += chr.size();
+      *o++ = '\t';
+      o = put_u64(o, H.pos0 + 1);
+      memcpy(o, "\t255\t", 5); o += 5;
+      o = put_u64(o, L);
+      memcpy(o, "M\t*\t0\t0\t", 8); o += 8;
+      memcpy(o, H.is_rc ? q.seq.p : rc_seq.data(), L); o += L;
+      *o++ = '\t';
+      memcpy(o, H.is_rc ? q.qual.p : rev_qual.data(), QL); o += QL;
+      *o++ = '\t';
+      o = put_u64(o, (uint64_t)nh);
+      *o++ = '\t';
+      *o++ = '\n';
+      out.n = (size_t)(o - out.p);
     }
   }
+  return true;
 }
 
 }  // namespace sbwt
@@ -155,7 +202,7 @@ class AsyncWriter {
  public:
   explicit AsyncWriter(FILE* f) : f_(f), th_([this] { run(); }) {}
   ~AsyncWriter() { finish(); }
-  void push(std::vector<std::string>&& bufs) {
+  void push(std::vector<TextBuf>&& bufs) {
     std::unique_lock<std::mutex> lk(m_);
     cv_.wait(lk, [this] { return q_.size() < 2; });  // at most two batches of text in flight
     q_.push_back(std::move(bufs));
@@ -175,7 +222,7 @@ class AsyncWriter {
  private:
   void run() {
     for (;;) {
-      std::vector<std::string> bufs;
+      std::vector<TextBuf> bufs;
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return !q_.empty() || done_; });
@@ -185,13 +232,13 @@ class AsyncWriter {
         cv_.notify_all();
       }
       for (auto& b : bufs)
-        if (!b.empty() && fwrite(b.data(), 1, b.size(), f_) != b.size()) ok_ = false;
+        if (b.n && fwrite(b.p, 1, b.n, f_) != b.n) ok_ = false;
     }
   }
   FILE* f_;
   std::mutex m_;
   std::condition_variable cv_;
-  std::deque<std::vector<std::string>> q_;
+  std::deque<std::vector<TextBuf>> q_;
   bool done_ = false;
   bool ok_ = true;
   std::thread th_;
@@ -221,12 +268,18 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
     return SBWT_ERR_IO;
   }
   uint64_t st[5] = {0, 0, 0, 0, 0};
+  const bool timing = getenv("SBWT_TIMING") != nullptr;  // per-phase wall time on stderr
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};                // census, parse, pack, map, format, wait for the writer
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](int k) { const double t = now(); t_phase[k] += t - t_mark; t_mark = t; };
   const uint64_t kBatch = 4u << 20;
   sbwt_ctx* ctx = nullptr;
   int rc = sbwt_ctx_create(ix, kBatch, &ctx);
   const char* p = fq.data() ? reinterpret_cast<const char*>(fq.data()) : nullptr;
   LineIndex lines;
   if (p) lines.build(p, fq.size(), n_threads);
+  lap(0);
   // a record counts only when all four of its lines are newline-terminated (fastq_reader_impl.hpp:94-98)
   const uint64_t n_records = lines.total_lines() / 4;
   std::vector<Record> recs;
@@ -259,6 +312,7 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
         parse_work(0);
         for (auto& x : th) x.join();
       }
+      lap(1);
       uint32_t longest = 0;
       for (uint32_t v : max_len) longest = std::max(longest, v);
       const uint32_t wpr = sbwt_words_per_read(longest);
@@ -282,6 +336,7 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
         pack_work(0);
         for (auto& x : th) x.join();
       }
+      lap(2);
       uint64_t n_ok = nr;
       int bad = 0;
       for (int t = 0; t < n_threads; ++t)
@@ -298,15 +353,25 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
                               hits.size(), &n_hits);
         }
         if (rc != SBWT_OK) break;
-        std::vector<std::string> bufs((size_t)n_threads);
+        lap(3);
+        std::vector<TextBuf> bufs((size_t)n_threads);
+        std::vector<char> fmt_ok((size_t)n_threads, 1);
         auto fmt_work = [&](int t) {
           const uint64_t a = n_ok * (uint64_t)t / (uint64_t)n_threads, b = n_ok * (uint64_t)(t + 1) / (uint64_t)n_threads;
-          format_range(ix, recs.data(), res.data(), hits.data(), a, b, bufs[(size_t)t]);
+          // one SAM line of a 50-bp read is about 150 bytes
+          bufs[(size_t)t].room((size_t)(b - a) * 160 + 4096);
+          fmt_ok[(size_t)t] = format_range(ix, recs.data(), res.data(), hits.data(), a, b, bufs[(size_t)t]);
         };
         std::vector<std::thread> th;
         for (int t = 1; t < n_threads; ++t) th.emplace_back(fmt_work, t);
         fmt_work(0);
         for (auto& x : th) x.join();
+        lap(4);
+        if (std::find(fmt_ok.begin(), fmt_ok.end(), 0) != fmt_ok.end()) {
+          set_error("out of host memory while formatting SAM text");
+          rc = SBWT_ERR_NOMEM;
+          break;
+        }
         writer.push(std::move(bufs));
         for (uint64_t k = 0; k < n_ok; ++k) {  // searcher.hpp:353-370
           const int32_t nh = res[k].nh;
@@ -327,7 +392,11 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
       }
     }
     write_ok = writer.finish();
+    lap(5);
   }
+  if (timing)
+    fprintf(stderr, "[sbwt timing] census %.3f parse %.3f pack %.3f map %.3f format %.3f writer+stats %.3f s\n", t_phase[0],
+            t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
   if (ctx) sbwt_ctx_free(ctx);
   if (!write_ok && rc == SBWT_OK) { set_error("write error on SAM output"); rc = SBWT_ERR_IO; }
   if (to_stdout) fflush(out); else if (fclose(out) != 0 && rc == SBWT_OK) { set_error("write error on SAM output"); rc = SBWT_ERR_IO; }

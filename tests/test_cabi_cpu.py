@@ -48,6 +48,32 @@ def test_pack_reads_encoding(L):
     assert int(packed[1, 4]) == (1 << 12) - 1 and int(packed[1, 3]) == 0xFFFFFFFF
 
 
+def test_pack_reads_every_length_and_every_byte(L):
+    """the packer works eight bases at a time: all tail lengths, and every byte value in every lane"""
+    rng = np.random.default_rng(5)
+    reads = ["".join("ACGT"[c] for c in rng.integers(0, 4, n)) for n in range(12, 131)]
+    packed, lens = api.pack_reads(reads)
+    for r, s in enumerate(reads):
+        got = [(int(packed[r, j >> 4]) >> (2 * (j & 15))) & 3 for j in range(len(s))]
+        assert got == ["ACGT".index(ch) for ch in s], "length %d" % len(s)
+        tail = [(int(packed[r, j >> 4]) >> (2 * (j & 15))) & 3 for j in range(len(s), packed.shape[1] * 16)]
+        assert not any(tail)
+    base = "ACGTTGCAACGTGGATCCAT" * 2
+    h = C.c_uint64()
+    out = np.zeros(4, np.uint32)
+    ln = np.zeros(1, np.uint32)
+    for pos in range(0, 40):
+        for b in range(1, 256):
+            if chr(b) in "ACGT":
+                continue
+            s = bytearray(base.encode())
+            s[pos] = b
+            off = np.array([0, len(s)], np.uint64)
+            rc = L.sbwt_pack_reads(bytes(s), off.ctypes.data_as(C.c_void_p), 1, 4, out.ctypes.data_as(C.c_void_p),
+                                   ln.ctypes.data_as(C.c_void_p), C.byref(h))
+            assert rc == -5, (pos, b)
+
+
 def test_pack_reads_rejects_what_upstream_aborts_on(L):
     with pytest.raises(api.SbwtError) as e:
         api.pack_reads(["ACGTACGTACGTACGT", "ACGTNACGTACGTACGT"])
