@@ -153,6 +153,13 @@ int sbwt_map_batch(sbwt_ctx *ctx, const uint32_t *packed, const uint32_t *lens, 
                    uint32_t words_per_read, int limit, int strand, sbwt_read_result *results,
                    sbwt_hit *hits, uint64_t hits_cap, uint64_t *n_hits);
 
+/* Page-locked host memory for the buffers handed to sbwt_map_batch: the copies then run as direct DMA at the
+ * link's rate instead of through the runtime's staging of pageable memory (DESIGN.md section 4 has both rates).
+ * Upstream has no counterpart (its vectors never leave the host, searcher.hpp:346-372).  Free with
+ * sbwt_host_free.  Any other host memory is accepted by sbwt_map_batch too. */
+int sbwt_host_alloc(uint64_t bytes, void **out);
+void sbwt_host_free(void *p);
+
 /* Milliseconds the kernels of the last sbwt_map_batch* call on this ctx took, measured with HIP events
  * on the ctx stream: [0] whole device pass, [1] search+unique-locate kernel, [2] multi-hit locate. */
 int sbwt_ctx_last_timing(const sbwt_ctx *ctx, float ms[3]);

@@ -82,6 +82,9 @@ def lib():
     L.sbwt_pack_reads.argtypes = [vp, vp, u64, u32, vp, vp, p(u64)]
     L.sbwt_map_batch_device.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_map_batch.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
+    L.sbwt_host_alloc.argtypes = [u64, p(vp)]
+    L.sbwt_host_free.argtypes = [vp]
+    L.sbwt_host_free.restype = None
     L.sbwt_ctx_last_timing.argtypes = [vp, p(C.c_float * 3)]
     L.sbwt_ctx_last_stats.argtypes = [vp, p(u64 * 4)]
     L.sbwt_ctx_stream.argtypes = [vp]
@@ -100,6 +103,32 @@ def device_count():
     n = C.c_int(0)
     _check(lib().sbwt_device_count(C.byref(n)))
     return n.value
+
+
+class PinnedBuffer:
+    """sbwt_host_alloc: page-locked host memory, viewed as numpy arrays (keep the buffer alive while they are used)"""
+
+    def __init__(self, nbytes):
+        ptr = C.c_void_p()
+        _check(lib().sbwt_host_alloc(int(nbytes), C.byref(ptr)))
+        self.ptr, self.nbytes = ptr.value, int(nbytes)
+
+    def array(self, dtype, count, offset=0):
+        dtype = np.dtype(dtype)
+        assert offset + count * dtype.itemsize <= self.nbytes
+        raw = (C.c_char * (count * dtype.itemsize)).from_address(self.ptr + offset)
+        return np.frombuffer(raw, dtype=dtype, count=count)
+
+    def close(self):
+        if self.ptr:
+            lib().sbwt_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def words_per_read(max_len):
@@ -220,12 +249,20 @@ class Context:
         self._h = C.c_void_p()
         _check(lib().sbwt_ctx_create(index._h, int(max_reads), C.byref(self._h)))
 
-    def map_batch(self, packed, lens, limit=1000, strand=2, hits_cap=None):
-        """Host-buffer entry point. Returns (results structured array, hits structured array)."""
+    def map_batch(self, packed, lens, limit=1000, strand=2, hits_cap=None, out=None):
+        """Host-buffer entry point. Returns (results structured array, hits structured array).
+        out = (results, hits) arrays to fill instead of fresh ones (e.g. views of a PinnedBuffer)."""
         packed = np.ascontiguousarray(packed, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         n = lens.size
         wpr = packed.shape[1] if packed.ndim == 2 else packed.size // max(n, 1)
+        if out is not None:
+            res, hits = out
+            assert res.dtype == RESULT_DTYPE and hits.dtype == HIT_DTYPE and res.size >= n
+            nh = C.c_uint64(0)
+            _check(lib().sbwt_map_batch(self._h, packed.ctypes.data, lens.ctypes.data, n, wpr, limit, strand,
+                                        res.ctypes.data, hits.ctypes.data, hits.size, C.byref(nh)))
+            return res[:n], hits[: nh.value]
         res = np.zeros(n, dtype=RESULT_DTYPE)
         cap = int(hits_cap if hits_cap is not None else max(2 * n, 1024))
         while True:

@@ -197,6 +197,30 @@ struct LineIndex {
   }
 };
 
+// page-locked host array (sbwt_host_alloc): the batch buffers cross PCIe as direct DMA
+template <typename T>
+struct PinnedArr {
+  T* p = nullptr;
+  uint64_t cap = 0;
+  PinnedArr() = default;
+  PinnedArr(const PinnedArr&) = delete;
+  PinnedArr& operator=(const PinnedArr&) = delete;
+  ~PinnedArr() { sbwt_host_free(p); }
+  int ensure(uint64_t count) {  // contents are not kept
+    if (count <= cap) return SBWT_OK;
+    sbwt_host_free(p);
+    p = nullptr;
+    cap = 0;
+    void* q = nullptr;
+    if (int rc = sbwt_host_alloc(count * sizeof(T), &q)) return rc;
+    p = static_cast<T*>(q);
+    cap = count;
+    return SBWT_OK;
+  }
+  T* data() { return p; }
+  T& operator[](uint64_t k) { return p[k]; }
+};
+
 // SAM text leaves through one writer thread, in order, while the next batch is parsed and mapped
 class AsyncWriter {
  public:
@@ -283,9 +307,9 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
   // a record counts only when all four of its lines are newline-terminated (fastq_reader_impl.hpp:94-98)
   const uint64_t n_records = lines.total_lines() / 4;
   std::vector<Record> recs;
-  std::vector<uint32_t> packed, lens;
-  std::vector<sbwt_read_result> res;
-  std::vector<sbwt_hit> hits;
+  PinnedArr<uint32_t> packed, lens;
+  PinnedArr<sbwt_read_result> res;
+  PinnedArr<sbwt_hit> hits;
   bool write_ok = true;
   {
     AsyncWriter writer(out);
@@ -316,9 +340,10 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
       uint32_t longest = 0;
       for (uint32_t v : max_len) longest = std::max(longest, v);
       const uint32_t wpr = sbwt_words_per_read(longest);
-      packed.resize(nr * wpr);
-      lens.resize(nr);
-      res.resize(nr);
+      if (rc == SBWT_OK) rc = packed.ensure(nr * wpr);
+      if (rc == SBWT_OK) rc = lens.ensure(nr);
+      if (rc == SBWT_OK) rc = res.ensure(nr);
+      if (rc != SBWT_OK) break;
       // pack on n_threads; the earliest offending read wins, as the upstream serial loop would hit it first
       std::vector<uint64_t> bad_at((size_t)n_threads, ~0ull);
       std::vector<int> bad_rc((size_t)n_threads, 0);
@@ -344,13 +369,13 @@ extern "C" int sbwt_map_fastq(const sbwt_index* ix, const char* fastq_path, cons
       // upstream processes (and prints) every read before the offending one, then aborts
       uint64_t n_hits = 0;
       if (n_ok) {
-        if (hits.size() < n_ok * 2) hits.resize(n_ok * 2);
+        if ((rc = hits.ensure(n_ok * 2)) != SBWT_OK) break;
         rc = sbwt_map_batch(ctx, packed.data(), lens.data(), n_ok, wpr, limit, strand, res.data(), hits.data(),
-                            hits.size(), &n_hits);
+                            hits.cap, &n_hits);
         if (rc == SBWT_ERR_CAPACITY) {
-          hits.resize(n_hits + 16);
+          if ((rc = hits.ensure(n_hits + 16)) != SBWT_OK) break;
           rc = sbwt_map_batch(ctx, packed.data(), lens.data(), n_ok, wpr, limit, strand, res.data(), hits.data(),
-                              hits.size(), &n_hits);
+                              hits.cap, &n_hits);
         }
         if (rc != SBWT_OK) break;
         lap(3);

@@ -367,6 +367,17 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   return SBWT_OK;
 }
 
+extern "C" int sbwt_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return SBWT_ERR_ARG;
+  *out = nullptr;
+  SBWT_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return SBWT_OK;
+}
+
+extern "C" void sbwt_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 template <typename T>
 static int ensure(T** p, uint64_t* have, uint64_t need) {
   if (*have >= need) return 0;
