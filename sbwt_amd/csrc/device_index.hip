@@ -471,8 +471,15 @@ __global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, 
   const uint32_t kmer = (uint32_t)v & 0xFFFFFFu;
   uint64_t lo = ix.c_functions[kmer], hi = ix.c_functions[kmer + 1];
   bool alive = lo < hi;
-  for (uint32_t t = kKmer; alive && t < K; t += 2)
+  uint32_t t = kKmer;
+  for (; alive && t + 2 <= K; t += 2)
     alive = step_two_bases(ix, ((uint32_t)(v >> (2 * t)) & 15u) ^ 15u, lo, hi);
+  if (alive && t < K) {  // odd order: the last base alone
+    const uint32_t c = (uint32_t)(v >> (2 * t)) & 3u;  // v holds complemented codes: the query is RC(read)
+    const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
+    lo = l1;
+    hi = h1;
+  }
   uint64_t width = hi > lo ? hi - lo : 0;
   if (width >= kKmerWide) { width = kKmerWide; lo = 0; }
   uint64_t entry = lo | (width << kPosBits);
@@ -618,14 +625,25 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   d.blocks2 = blocks2;
   d.sb_abs = sb_abs;
   {
-    // widest even order K <= 16 whose 4^K entries do not outnumber the suffixes (GRCh38: 16, dm6: 14, E. coli:
-    // none); SBWT_KMER_ORDER overrides (12 = none)
+    // widest order K <= 17 whose 4^K entries are at most 16 per suffix (beyond that nearly every K-mer that occurs
+    // is a single row already) and whose table leaves kKmerHeadroom of this device's memory free (GRCh38: 17,
+    // 137 GB; dm6: 16; E. coli: 13); SBWT_KMER_ORDER overrides (12 = none)
     uint32_t K = kKmer;
-    while (K + 2 <= 16 && (1ull << (2 * (K + 2))) <= raw.n) K += 2;
+    size_t free_b = 0, total_b = 0;
+    SBWT_HIP(hipMemGetInfo(&free_b, &total_b));
+    constexpr uint64_t kKmerHeadroom = 24ull << 30;
+    for (uint32_t k = kKmer + 1; k <= kMaxKmerOrder; ++k) {
+      const uint64_t entries = 1ull << (2 * k);
+      if (entries > 16 * raw.n || entries * 8 + kKmerHeadroom > (uint64_t)free_b) break;
+      K = k;
+    }
     if (const char* e = getenv("SBWT_KMER_ORDER")) {
       const int want = atoi(e);
-      if (want >= kKmer && want <= 16 && (want & 1) == 0) K = (uint32_t)want;
+      if (want >= kKmer && want <= (int)kMaxKmerOrder) K = (uint32_t)want;
     }
+    if (getenv("SBWT_DEBUG"))
+      fprintf(stderr, "[sbwt debug] device memory: %.1f GB free of %.1f GB before the prefix table; order %u (%.1f GB)\n",
+              free_b / 1e9, total_b / 1e9, K, K > (uint32_t)kKmer ? 8.0 * (double)(1ull << (2 * K)) / 1e9 : 0.0);
     d.kmer_order = K;
     d.kmer_tab = nullptr;
     if (K > (uint32_t)kKmer) {

@@ -43,6 +43,7 @@ constexpr uint64_t kNoPosition = ~0ull;  // sa_full sentinel: the upstream uniqu
 // positions p, p-1, ..., p-run+1 whose rows are LF-consistent (see device_index.hip, k_verify_rows), i.e. how far
 // a size-1 interval can be carried by text comparison instead of rank queries.
 constexpr uint64_t kKmerWide = (1ull << 24) - 1;
+constexpr uint32_t kMaxKmerOrder = 17;  // widest memoised search prefix (4^17 entries of 8 B = 137 GB)
 // kmer_tab entry of a prefix whose interval is ONE row that sa_full locates: bit 63, text position (low 40 bits),
 // run (23 bits, saturating) -- the search goes straight to the text comparison, without the sa_full access
 constexpr uint64_t kKmerLocated = 1ull << 63;

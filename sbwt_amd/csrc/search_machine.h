@@ -34,7 +34,7 @@ enum SmState : uint32_t {
   S_FIN,        // nothing to load: the search of a prefetched read was over at once
   S_START,      // between reads: waits for room in the result ring, then starts its reserved read
 };
-enum SmMode : uint32_t { M_LAST = 0, M_REPLAY = 1, M_DEAD = 2 };
+enum SmMode : uint32_t { M_LAST = 0, M_REPLAY = 1, M_DEAD = 2, M_STEP = 3 };
 
 struct SmTables {  // LDS copies (or the global originals when they do not fit)
   const uint64_t* chr;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   const uint64_t range_begin = wave * chunk;
   const uint64_t range_end = range_begin + chunk < a.n_reads ? range_begin + chunk : a.n_reads;
   const uint32_t K = ix.kmer_order;
-  const uint32_t kmask = K >= 16u ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+  const uint64_t kmask = (1ull << (2 * K)) - 1ull;  // K <= kMaxKmerOrder: the prefix lies in the first 32 bases, w_lo
   const uint32_t max_len = a.wpr * 16u;
 
   // lane state.  A lane holds its current read r and has RESERVED its next one, rn: lanes that finish in the same
@@ -210,9 +210,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     } else {
       aux &= ~A_PIECE;
       const uint64_t wsel = (j & 32u) ? w_hi : w_lo;
-      if (j + 1 == L) {
+      if (j + 1 == L || (j & 1u)) {
+        // the last base, or the base after a prefix of odd order: two-base steps start at even j, so that the
+        // pair never straddles the halves or the pieces of the read record
         const uint32_t c = ((uint32_t)(wsel >> (2 * (j & 31u))) & 3u) ^ 3u;
-        aux = (aux & ~0x3ffu) | c | (M_LAST << 8);
+        aux = (aux & ~0x3ffu) | c | ((j + 1 == L ? M_LAST : M_STEP) << 8);
         st = S_LF1;
       } else {
         const uint32_t two = ((uint32_t)(wsel >> (2 * (j & 31u))) & 15u) ^ 15u;  // complement: the query is RC(read)
@@ -289,12 +291,12 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         free_r = false;
         break;
       case S_KMER: {
-        const uint32_t cw = ~(uint32_t)w_lo;  // complemented codes of bases 0..15
+        const uint64_t cw = ~w_lo;  // complemented codes of bases 0..31
         tally += 1;
         if (ix.kmer_tab && L >= K) {
           pc = ix.kmer_tab + (cw & kmask);
         } else {
-          pc = ix.c_functions + (cw & 0xFFFFFFu);
+          pc = ix.c_functions + ((uint32_t)cw & 0xFFFFFFu);
           pe = pc + 1;
           pair = true;
           free_e = false;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           aux |= A_REQ_W;
         }
       } else if (!(aux & A_HAVE_K) && ix.kmer_tab && nL >= K && nL <= max_len) {
-        pe = ix.kmer_tab + ((~(uint32_t)nw_lo) & kmask);
+        pe = ix.kmer_tab + ((~nw_lo) & kmask);
         aux |= A_REQ_K;
         tally += 1;
       }
@@ -466,9 +468,9 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         } else {
           lo = l1;
           hi = h1;
-          if (mode == M_LAST) j += 1;
+          if (mode == M_LAST || mode == M_STEP) j += 1;
         }
-        finish = true;
+        finish = mode == M_STEP ? choose() : true;
         break;
       }
       case S_SA: {

@@ -43,10 +43,11 @@ def sb():
     return sbwt_amd
 
 
-@pytest.fixture(scope="module", params=["12", "14", "16"])
+@pytest.fixture(scope="module", params=["12", "13", "14", "15", "16"])
 def loaded(request, sb, oracle, golden_indexes):
-    """every test runs with no memoised search prefix (12) and with the 14- and 16-base tables the loader would
-    pick for dm6- and GRCh38-sized indexes (forced here: the golden genomes are tiny)"""
+    """every test runs with no memoised search prefix (12) and with the 13- to 16-base tables the loader picks for
+    larger indexes (forced here: the golden genomes are tiny); odd orders take one single-base step after the
+    prefix; order 17, what a GRCh38-sized index gets, has a test of its own below (its table is 137 GB)"""
     os.environ["SBWT_KMER_ORDER"] = request.param
     out = {}
     for g, prefix in golden_indexes.items():
@@ -56,6 +57,43 @@ def loaded(request, sb, oracle, golden_indexes):
     for ix, oix in out.values():
         ix.close()
         oix.close()
+
+
+def test_order_17_prefix_table(sb, oracle, golden_indexes, golden_dir):
+    """the 4^17-entry table (34-bit entry numbers) on the repeat genome: golden reads, every length 12..60 on
+    both strands, substitutions"""
+    os.environ["SBWT_KMER_ORDER"] = "17"
+    try:
+        ix = sb.Index.load(golden_indexes["g2"])
+    finally:
+        os.environ.pop("SBWT_KMER_ORDER")
+    oix = oracle.OracleIndex.load(golden_indexes["g2"])
+    chroms = []
+    for line in open(os.path.join(golden_dir, "g2.fa")):
+        if line.startswith(">"):
+            chroms.append("")
+        else:
+            chroms[-1] += line.strip().upper()
+    seq = chroms[0].replace("N", "")
+    rng = np.random.default_rng(17)
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
+    for L in list(range(12, 61)) + [64, 65, 100, 129]:
+        for _ in range(24):
+            p = int(rng.integers(0, len(seq) - L))
+            s = seq[p:p + L]
+            if rng.random() < 0.5:
+                s = s.translate(comp)[::-1]
+            if rng.random() < 0.4:
+                q = int(rng.integers(0, L))
+                s = s[:q] + "ACGT"[int(rng.integers(0, 4))] + s[q + 1:]
+            reads.append(s)
+    ctx = sb.Context(ix, len(reads))
+    for strand in (2, 0, 1):
+        assert_same(sb, ctx, oix, reads, strand=strand)
+    ctx.close()
+    ix.close()
+    oix.close()
 
 
 @pytest.mark.parametrize("g", ["g1", "g2"])
