@@ -193,7 +193,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, ix->device);
     const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
-    const size_t ring_bytes = (size_t)4 * kSmRing * 32;  // four waves per workgroup
+    const size_t ring_bytes = (size_t)4 * kSmRing * 16;  // four waves per workgroup
     c->sm_ring_bytes = ring_bytes;
     if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys && n_super <= kSmMaxSuper)
       c->sm_lds_bytes = (((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super + 1) & ~(size_t)1) * sizeof(uint64_t);

@@ -80,34 +80,41 @@ struct SmArgs {
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
 constexpr uint32_t kSmMaxSuper = 16;    // superblocks of sb_abs staged in LDS (2^35 suffixes)
-constexpr uint32_t kSmRing = 256;       // results staged per wave (LDS, 32 B each) before they are written as whole lines
-// ring entry word 3 ("meta")
-constexpr uint32_t R_NH = 1u, R_RC = 2u, R_MULTI = 4u;  // bits 8.. = flags
+constexpr uint32_t kSmRing = 512;       // results staged per wave (LDS, 16 B each) before they are written as whole lines
+// ring entry: word 0 = sa_lo | (sa_hi - sa_lo) << 40 (24 bits), word 1 = payload (40 bits) | chr_id << 40 (16 bits) |
+// meta << 56.  A result that does not fit (interval of 2^24 rows or more, chr_id above 65535) is written to global
+// memory at once and its entry only says so.
+constexpr uint32_t R_NH = 1u, R_RC = 2u, R_MULTI = 4u, R_FLAGS_SHIFT = 3u /* 2 bits */, R_INVALID = 32u, R_DIRECT = 64u;
+constexpr uint64_t kRingWidthMax = 0xFFFFFFull;
 
-// one finished read leaves the ring: lane l writes read first + l, so a wave writes 2 KB of results and 1 KB of hits
-// as whole lines
-__device__ __forceinline__ void sm_flush(const SmArgs& a, const uint4* ring, uint64_t range_begin, uint64_t first,
-                                         uint64_t rd, bool valid) {
-  if (!valid) return;
-  const uint4* e = ring + (size_t)((rd - range_begin) & (kSmRing - 1)) * 2;
-  const uint4 e0 = e[0], e1 = e[1];
-  const uint32_t meta = e1.w;
-  const uint64_t payload = ((uint64_t)e1.y << 32) | e1.x;
+__device__ __forceinline__ void sm_emit(const SmArgs& a, uint64_t rd, uint64_t lo, uint64_t hi, uint64_t payload,
+                                        uint32_t chr_id, uint32_t meta) {
   sbwt_read_result res;
-  res.sa_lo = ((uint64_t)e0.y << 32) | e0.x;
-  res.sa_hi = ((uint64_t)e0.w << 32) | e0.z;
+  res.sa_lo = lo;
+  res.sa_hi = hi;
   res.first_hit = (meta & R_NH) ? rd : ((meta & R_MULTI) ? payload : 0);
   res.nh = (meta & R_NH) ? 1 : 0;
-  res.flags = ((meta >> 8) & 3u) | (meta & kFlagInvalid);
+  res.flags = ((meta >> R_FLAGS_SHIFT) & 3u) | ((meta & R_INVALID) ? kFlagInvalid : 0u);
   a.results[rd] = res;
   if (meta & R_NH) {  // unique hits live at the read's own index
     sbwt_hit h;
     h.pos0 = payload;
-    h.chr_id = e1.z;
+    h.chr_id = chr_id;
     h.is_rc = (meta & R_RC) ? 1u : 0u;
     a.hits[rd] = h;
   }
-  (void)first;
+}
+
+// one finished read leaves the ring: lane l writes read first + l, so a wave writes 2 KB of results and 1 KB of hits
+// as whole lines
+__device__ __forceinline__ void sm_flush(const SmArgs& a, const uint4* ring, uint64_t range_begin, uint64_t rd, bool valid) {
+  if (!valid) return;
+  const uint4 e = ring[(size_t)((rd - range_begin) & (kSmRing - 1))];
+  const uint64_t e0 = ((uint64_t)e.y << 32) | e.x, e1 = ((uint64_t)e.w << 32) | e.z;
+  const uint32_t meta = (uint32_t)(e1 >> 56);
+  if (meta & R_DIRECT) return;
+  const uint64_t lo = e0 & kPosMask;
+  sm_emit(a, rd, lo, lo + (e0 >> kPosBits), e1 & kPosMask, (uint32_t)(e1 >> kPosBits) & 0xFFFFu, meta);
 }
 
 // aux bits above the state-private low 10
@@ -115,11 +122,13 @@ constexpr uint32_t A_TRIED = 1u << 16;    // sa_full was consulted for the text 
 constexpr uint32_t A_LOCATED = 1u << 17;  // p holds the final text position
 constexpr uint32_t A_NOPOS = 1u << 18;    // the upstream locate reports nothing for this row
 constexpr uint32_t A_PIECE = 1u << 19;    // w holds the read piece j is in (set by S_REFETCH)
-constexpr uint32_t A_HAVE_W = 1u << 20;   // the lane's NEXT read is prefetched (nw_lo, nw_hi, nL)
-constexpr uint32_t A_HAVE_K = 1u << 21;   // ... and so is its search-prefix entry (nk)
-constexpr uint32_t A_REQ_W = 1u << 22;    // prefetch in flight this iteration
-constexpr uint32_t A_REQ_K = 1u << 23;
+constexpr uint32_t A_CUR_W = 1u << 20;    // S_START: the read's record was prefetched (w_lo, w_hi, L)
+constexpr uint32_t A_CUR_K = 1u << 21;    // ... and so was its search-prefix entry (ck)
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
+
+// prefetch pipeline of a lane: its next read (1) and the one after (2)
+constexpr uint32_t PF_W1 = 1u, PF_K1 = 2u, PF_W2 = 4u;        // record of 1, prefix entry of 1, record of 2 are here
+constexpr uint32_t PF_RW1 = 8u, PF_RK1 = 16u, PF_RW2 = 32u;   // ... are in flight this iteration
 
 template <bool kLds>
 __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   }
   // per-wave ring of finished reads (after the tables; 16-byte aligned)
   const uint32_t table_words = kLds ? ((ix.n_chr + 2 * ix.n_npos + 16 * n_super + 1) & ~1u) : 0u;
-  uint4* const ring = reinterpret_cast<uint4*>(s_mem + table_words) + (size_t)(threadIdx.x >> 6) * kSmRing * 2;
+  uint4* const ring = reinterpret_cast<uint4*>(s_mem + table_words) + (size_t)(threadIdx.x >> 6) * kSmRing;
   // the wave's contiguous range of reads; lane l owns reads begin + l, begin + l + 64, ...
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -152,19 +161,24 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   const uint64_t kmask = (1ull << (2 * K)) - 1ull;  // K <= kMaxKmerOrder: the prefix lies in the first 32 bases, w_lo
   const uint32_t max_len = a.wpr * 16u;
 
-  // lane state.  A lane holds its current read r and has RESERVED its next one, rn: lanes that finish in the same
-  // iteration reserve consecutive reads (ballot order), so the records they prefetch and, since such lanes tend to
-  // finish together again, the results they write fall into the same lines.
-  uint64_t r = range_begin + lane, rn = r + 64;
-  uint64_t next = range_begin + 128;  // wave-uniform: first unreserved read
+  // lane state.  A lane holds its current read r and has RESERVED its next two, rn and rn2: lanes that start a read
+  // in the same iteration reserve consecutive reads (ballot order), so the records they prefetch and, since such
+  // lanes tend to finish together again, the results they write fall into the same lines.  A read is a chain of
+  // three dependent loads at least (record, prefix entry, text + final row): with two reads reserved ahead, the
+  // record of rn2 and the prefix entry of rn ride in slots the current state leaves idle, and a read whose
+  // prefix entry is a located row takes ONE iteration.
+  uint64_t r = range_begin + lane, rn = r + 64, rn2 = r + 128;
+  uint64_t next = range_begin + 192;  // wave-uniform: first unreserved read
   uint32_t st = r < range_end ? S_FETCH : S_IDLE;
   bool reserve = false;
   uint64_t flushed = range_begin;  // wave-uniform: results of reads below it are in global memory
   uint32_t tally = 0;              // random index accesses this lane needed (128-byte lines)
   uint64_t wave_slots = 0;  // wave-uniform: hit slots handed to the multi-hit reads of this wave so far
   uint32_t wave_multi = 0;  // wave-uniform: how many such reads
-  uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0;
-  uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0, nw_lo = 0, nw_hi = 0, nk = 0;
+  uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0, mL = 0, pf = 0;
+  uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0;
+  uint64_t ck = 0;                                     // prefix entry of the read about to start
+  uint64_t nw_lo = 0, nw_hi = 0, nk = 0, mw_lo = 0, mw_hi = 0;  // records of rn (with its prefix entry) and rn2
 
   // interval after the search prefix, from a kmer_tab entry (device_layout.h)
   auto apply_prefix = [&](uint64_t e) {
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     for (;;) {
       const uint64_t cur = st == S_IDLE ? ~0ull : r;
       if (flushed + 64 > range_end || __any(cur < flushed + 64)) break;
-      sm_flush(a, ring, range_begin, flushed, flushed + lane, true);
+      sm_flush(a, ring, range_begin, flushed + lane, true);
       flushed += 64;
     }
     // ---- start: a lane between reads takes its reserved one once the ring has room for it
@@ -242,19 +256,16 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       const uint32_t had = aux;
       aux = 0;
       flags = 0;
-      if (!(had & A_HAVE_W)) {
+      if (!(had & A_CUR_W)) {
         st = S_FETCH;
       } else {
-        w_lo = nw_lo;
-        w_hi = nw_hi;
-        L = nL;
         j = kKmer;
         if (L < (uint32_t)kKmer || L > max_len) {
           flags = kFlagInvalid;
           lo = hi = 0;
           st = S_FIN;
-        } else if (had & A_HAVE_K) {
-          apply_prefix(nk);
+        } else if (had & A_CUR_K) {
+          apply_prefix(ck);
           if (choose()) st = S_FIN;
         } else {
           st = S_KMER;
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     {
       const uint64_t wm = __ballot(reserve);
       if (wm) {
-        if (reserve) rn = next + (uint64_t)__popcll(wm & lane_lt);
+        if (reserve) rn2 = next + (uint64_t)__popcll(wm & lane_lt);
         next += (uint64_t)__popcll(wm);
         reserve = false;
       }
@@ -281,9 +292,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint4* pr = idle16;    // 16 B (read piece)
     const uint64_t* pc = idle8;  // 8 B
     const uint64_t* pe = idle8;  // 8 B
+    const uint64_t* pk = idle8;  // 8 B (prefetch: prefix entry)
+    const uint64_t* pl = idle8;  // 8 B (prefetch: the aligned 8 bytes holding a length)
     const uint32_t* pd = a.packed;  // 4 B
     bool pair = false;           // S_KMER through the c_functions pair
-    bool free_r = true, free_e = true;
+    bool free_r = true;
     switch (st) {
       case S_FETCH:
         pr = reinterpret_cast<const uint4*>(rp);
@@ -299,7 +312,6 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           pc = ix.c_functions + ((uint32_t)cw & 0xFFFFFFu);
           pe = pc + 1;
           pair = true;
-          free_e = false;
         }
         break;
       }
@@ -319,7 +331,6 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         pc = &bl->cnt[aux & 3u];
         pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
         pe = &bh->cnt[aux & 3u];
-        free_e = false;
         tally += bl == bh ? 1u : 2u;
         break;
       }
@@ -356,18 +367,20 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       default:  // S_FIN, S_IDLE
         break;
     }
-    // the lane's NEXT read rides in slots this state leaves idle: first its record (16 B + the aligned 8 bytes
-    // holding its length), then its search-prefix entry, so that it starts at its first step
-    if (st != S_IDLE && free_e) {
-      if (!(aux & A_HAVE_W)) {
-        if (free_r && rn + 1 < a.n_reads && rn < range_end) {
-          pr = reinterpret_cast<const uint4*>(a.packed + rn * (uint64_t)a.wpr);
-          pe = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(a.lens + rn) & ~(uintptr_t)7);
-          aux |= A_REQ_W;
+    // the lane's next reads ride in slots this state leaves idle: the record of rn, or of rn2 once that of rn is
+    // here (16 B + the aligned 8 bytes holding its length), and the search-prefix entry of rn
+    if (st != S_IDLE) {
+      if (free_r) {
+        const uint64_t q = !(pf & PF_W1) ? rn : rn2;
+        if (!(pf & PF_W2) && q + 1 < a.n_reads && q < range_end) {
+          pr = reinterpret_cast<const uint4*>(a.packed + q * (uint64_t)a.wpr);
+          pl = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(a.lens + q) & ~(uintptr_t)7);
+          pf |= !(pf & PF_W1) ? PF_RW1 : PF_RW2;
         }
-      } else if (!(aux & A_HAVE_K) && ix.kmer_tab && nL >= K && nL <= max_len) {
-        pe = ix.kmer_tab + ((~nw_lo) & kmask);
-        aux |= A_REQ_K;
+      }
+      if ((pf & (PF_W1 | PF_K1)) == PF_W1 && ix.kmer_tab && nL >= K && nL <= max_len) {
+        pk = ix.kmer_tab + ((~nw_lo) & kmask);
+        pf |= PF_RK1;
         tally += 1;
       }
     }
@@ -375,18 +388,24 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     // into the per-state branches on either side, which would put a memory wait inside every branch.
     __builtin_amdgcn_wave_barrier();
     const uint4 va = *pa, vb = *pb, vr = *pr;
-    const uint64_t vc = *pc, ve = *pe;
+    const uint64_t vc = *pc, ve = *pe, vk = *pk, vl = *pl;
     const uint32_t vd = *pd;
     __builtin_amdgcn_wave_barrier();
 
-    if (aux & A_REQ_W) {
+    if (pf & PF_RW1) {
       nw_lo = u64_of(vr.x, vr.y);
       nw_hi = u64_of(vr.z, vr.w);
-      nL = (reinterpret_cast<uintptr_t>(a.lens + rn) & 4) ? (uint32_t)(ve >> 32) : (uint32_t)ve;
-      aux = (aux | A_HAVE_W) & ~A_REQ_W;
-    } else if (aux & A_REQ_K) {
-      nk = ve;
-      aux = (aux | A_HAVE_K) & ~A_REQ_K;
+      nL = (reinterpret_cast<uintptr_t>(a.lens + rn) & 4) ? (uint32_t)(vl >> 32) : (uint32_t)vl;
+      pf = (pf | PF_W1) & ~PF_RW1;
+    } else if (pf & PF_RW2) {
+      mw_lo = u64_of(vr.x, vr.y);
+      mw_hi = u64_of(vr.z, vr.w);
+      mL = (reinterpret_cast<uintptr_t>(a.lens + rn2) & 4) ? (uint32_t)(vl >> 32) : (uint32_t)vl;
+      pf = (pf | PF_W2) & ~PF_RW2;
+    }
+    if (pf & PF_RK1) {
+      nk = vk;
+      pf = (pf | PF_K1) & ~PF_RK1;
     }
 
     // ---- consume
@@ -589,13 +608,30 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         meta = R_MULTI;
       }
       // flags: bits 0..1 and bit 31 are in use
-      meta |= ((flags & 3u) << 8) | (flags & kFlagInvalid);
-      uint4* e = ring + (size_t)((r - range_begin) & (kSmRing - 1)) * 2;
-      e[0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-      e[1] = make_uint4((uint32_t)payload, (uint32_t)(payload >> 32), chr_id, meta);
+      meta |= ((flags & 3u) << R_FLAGS_SHIFT) | ((flags & kFlagInvalid) ? R_INVALID : 0u);
+      const uint64_t width = hi - lo;
+      if (hi < lo || width >= kRingWidthMax || chr_id > 0xFFFFu || payload > kPosMask) {
+        sm_emit(a, r, lo, hi, payload, chr_id, meta);  // does not fit a ring entry
+        meta = R_DIRECT;
+      }
+      const uint64_t e0 = lo | (width << kPosBits), e1 = payload | ((uint64_t)chr_id << kPosBits) | ((uint64_t)meta << 56);
+      ring[(size_t)((r - range_begin) & (kSmRing - 1))] =
+          make_uint4((uint32_t)e0, (uint32_t)(e0 >> 32), (uint32_t)e1, (uint32_t)(e1 >> 32));
 
-      // the lane's next read is the one it reserved; it starts at the top of the loop
+      // the lane moves on to the read it reserved first; what was prefetched for it becomes current, and the
+      // read after it moves up (its prefix entry is fetched from now on); the new rn2 is reserved at the start
       r = rn;
+      rn = rn2;
+      rn2 = ~0ull;
+      aux = ((pf & PF_W1) ? A_CUR_W : 0u) | ((pf & PF_K1) ? A_CUR_K : 0u);
+      w_lo = nw_lo;
+      w_hi = nw_hi;
+      L = nL;
+      ck = nk;
+      nw_lo = mw_lo;
+      nw_hi = mw_hi;
+      nL = mL;
+      pf = (pf & PF_W2) ? PF_W1 : 0u;
       st = r < range_end ? S_START : S_IDLE;
     }
   }
@@ -612,7 +648,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     if (lane == 0) atomicAdd(a.index_accesses, (unsigned long long)t);
   }
   // what is left in the ring
-  for (; flushed < range_end; flushed += 64) sm_flush(a, ring, range_begin, flushed, flushed + lane, flushed + lane < range_end);
+  for (; flushed < range_end; flushed += 64) sm_flush(a, ring, range_begin, flushed + lane, flushed + lane < range_end);
 }
 
 }  // namespace sbwt
