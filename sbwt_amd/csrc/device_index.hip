@@ -394,6 +394,53 @@ __global__ __launch_bounds__(256) void k_run_apply(uint64_t n, const uint8_t* __
   }
 }
 
+// 16 bases of textrc starting at x (zero where x < 0; the array is zero-padded past its end)
+__device__ __forceinline__ uint32_t textrc_word_at(const uint32_t* __restrict__ textrc, int64_t x) {
+  if (x >= 0) {
+    const uint64_t w = (uint64_t)x >> 4;
+    const uint32_t sh = 2 * (uint32_t)(x & 15);
+    const uint32_t lo = textrc[w], hi = textrc[w + 1];
+    return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+  }
+  uint32_t out = 0;
+  for (int t = 0; t < 16; ++t) {
+    const int64_t y = x + t;
+    if (y >= 0) out |= ((textrc[(uint64_t)y >> 4] >> (2 * (uint32_t)(y & 15))) & 3u) << (2 * t);
+  }
+  return out;
+}
+
+// one thread per PosLine (device_layout.h)
+__global__ __launch_bounds__(256) void k_pos_lines(DeviceIndex ix, const unsigned long long* __restrict__ row_tab,
+                                                   const uint32_t* __restrict__ textrc, PosLine* __restrict__ lines,
+                                                   uint64_t n_lines) {
+  const uint64_t line = global_thread();
+  if (line >= n_lines) return;
+  const uint64_t q0 = line * kPosPerLine;
+  const int64_t xs = (int64_t)ix.n - 2 - (int64_t)q0 - 127;
+  uint32_t text[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) text[w] = textrc_word_at(textrc, xs + 16 * w);
+  uint64_t rows[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) rows[k] = 0;
+#pragma unroll
+  for (int s = 0; s < (int)kPosPerLine; ++s) {
+    const uint64_t q = q0 + (uint64_t)s;
+    const uint64_t v = (q < ix.n ? (uint64_t)row_tab[q] : ~0ull) & kPosMask;
+    const int word = (40 * s) >> 6, sh = (40 * s) & 63;
+    rows[word] |= v << sh;
+    if (sh > 24) rows[word + 1] |= v >> (64 - sh);
+  }
+  uint4* out = reinterpret_cast<uint4*>(lines + line);
+  out[0] = make_uint4(text[0], text[1], text[2], text[3]);
+  out[1] = make_uint4(text[4], text[5], text[6], text[7]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    out[2 + k] = make_uint4((uint32_t)rows[2 * k], (uint32_t)(rows[2 * k] >> 32), (uint32_t)rows[2 * k + 1],
+                            (uint32_t)(rows[2 * k + 1] >> 32));
+}
+
 // ---- blocks2: two-step planes ----------------------------------------------------------------------
 // one wave per index block; lane j owns position 64b + j
 __global__ __launch_bounds__(256) void k_planes2(DeviceIndex ix, Block2* __restrict__ blocks2, uint64_t* special) {
@@ -586,8 +633,11 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     unsigned long long* row_tab = nullptr;
     uint32_t* textrc = nullptr;
     const uint64_t n_words = ((raw.n - 1 + 63) / 64) * 4 + 8;  // whole 16-byte pieces + 2 of padding: the comparison reads one piece ahead
-    if (int rc = dev_alloc(ix, &row_tab, raw.n)) return rc;
+    PosLine* pos_lines = nullptr;
+    const uint64_t n_lines = (raw.n + kPosPerLine - 1) / kPosPerLine;
     if (int rc = dev_alloc(ix, &textrc, n_words)) return rc;
+    if (int rc = dev_alloc(ix, &pos_lines, n_lines)) return rc;
+    SBWT_HIP(hipMalloc(&row_tab, raw.n * sizeof(uint64_t)));  // temporary: it leaves as pos_lines
     uint8_t* badpos = nullptr;
     uint64_t* chunk_last = nullptr;
     const uint64_t n_run_chunks = (raw.n + kRunChunk - 1) / kRunChunk;
@@ -605,9 +655,11 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     k_run_scan<<<1, 1024>>>(chunk_last, n_run_chunks);
     k_run_apply<<<grid_for(n_run_chunks, 256), 256>>>(raw.n, badpos, row_tab, chunk_last, sa_full);
     SBWT_LAUNCHED();
+    k_pos_lines<<<grid_for(n_lines, 256), 256>>>(d, row_tab, textrc, pos_lines, n_lines);
+    SBWT_LAUNCHED();
     SBWT_HIP(hipDeviceSynchronize());
-    hipFree(badpos); hipFree(chunk_last);
-    d.row_tab = reinterpret_cast<const uint64_t*>(row_tab);
+    hipFree(badpos); hipFree(chunk_last); hipFree(row_tab);
+    d.pos_lines = pos_lines;
     d.textrc = textrc;
   }
 

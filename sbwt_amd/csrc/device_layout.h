@@ -38,6 +38,19 @@ struct alignas(128) Block2 {
 static_assert(sizeof(Block2) == 128, "Block2 is one 128-byte granule");
 constexpr int kSuperShift = 31;  // superblock = 2^31 positions, so relative counts fit 32 bits
 
+// 128-byte line per 19 consecutive text positions q0 .. q0+18: what the END of a text comparison needs, in one
+// access.  rows: the row whose suffix starts at each position (inverse of sa_full, 40 bits each, little endian, at
+// byte 5 s).  text: the 128 bases textrc[xs .. xs + 128), xs = n - 2 - q0 - 127 (zero where x < 0), i.e. the text in
+// front of these positions as a read meets it: a read that ends its comparison on position q0 + s after `rem`
+// more bases compares them with the bases from offset 128 - (s + rem) on, whenever s + rem <= 128.
+constexpr uint32_t kPosPerLine = 19;
+struct alignas(128) PosLine {
+  uint32_t text[8];
+  uint8_t rows[96];
+};
+static_assert(sizeof(PosLine) == 128, "PosLine is one 128-byte granule");
+typedef uint64_t u64_a4 __attribute__((aligned(4)));  // 8-byte load from a 4-byte aligned address
+
 constexpr uint64_t kNoPosition = ~0ull;  // sa_full sentinel: the upstream unique-hit walk reports nothing
 // sa_full entry = text position (low 40 bits) | run (high 24 bits, saturating): the number of consecutive text
 // positions p, p-1, ..., p-run+1 whose rows are LF-consistent (see device_index.hip, k_verify_rows), i.e. how far
@@ -69,11 +82,11 @@ struct DeviceIndex {
   const uint64_t* sb_abs;   // [n_super][16]: K2[code] + #code before the superblock
   const uint64_t* loc_vals; // SA value of the k-th sampled position (location_table[k].second)
   const uint64_t* sa_full;  // memoised unique-hit locate: result of the upstream walk started at i (+ run, see above)
-  const uint64_t* row_tab;  // inverse of sa_full: row whose walk reports text position p (n entries, ~0 = none)
+  const PosLine* pos_lines; // inverse of sa_full (row whose walk reports text position p) + the text in front of it
   // memoised search prefix: entry v = interval after init_exact_match + exec_exact_match over the first kmer_order
   // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised; kKmerLocated form below)
   const uint64_t* kmer_tab; uint32_t kmer_order;  // kmer_order = 12: no table
-  const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row_tab[n-1-x]]
+  const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;
   const uint64_t* npos_key; const uint64_t* npos_val; uint32_t n_npos;

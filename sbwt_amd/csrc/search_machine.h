@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       if (rem >= 1 && run > rem && pos >= rem) {
         p = pos;
         j = K;
-        lo = 0;  // the row itself is not needed: a comparison that dies reads it from row_tab
+        lo = 0;  // the row itself is not needed: a comparison that dies reads it from pos_lines
         hi = 1;
         aux |= A_TRIED | A_DIRECT;
         return;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint4* pa = idle16;    // 16 B
     const uint4* pb = idle16;    // 16 B
     const uint4* pr = idle16;    // 16 B (read piece)
-    const uint64_t* pc = idle8;  // 8 B
+    const u64_a4* pc = idle8;    // 8 B (4-byte aligned when it points into a PosLine)
     const uint64_t* pe = idle8;  // 8 B
     const uint64_t* pk = idle8;  // 8 B (prefetch: prefix entry)
     const uint64_t* pl = idle8;  // 8 B (prefetch: the aligned 8 bytes holding a length)
@@ -340,26 +340,50 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         tally += 1;
         break;
       case S_CMP: {
-        const uint64_t x0 = ix.n - 1 - p;  // read[j + t] continues the match iff it equals textrc[x0 + t]
-        const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
-        pa = t4;
-        pb = t4 + 1;
+        // read[j + t] continues the match iff it equals textrc[x0 + t]; the last chunk also brings the final row
+        const uint64_t x0 = ix.n - 1 - p;
         const uint32_t piece_end = (j | 63u) + 1u;
-        const uint64_t x1 = x0 + ((piece_end < L ? piece_end : L) - j) - 1;  // last base compared
-        tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;                     // 512 bases per 128-byte line
+        uint32_t o = (uint32_t)(x0 & 63), sh = 0;
+        bool from_text = true;
         if (piece_end >= L) {
-          pc = ix.row_tab + (p - (uint64_t)(L - j));  // last chunk: the final row
+          const uint32_t rem = L - j;
+          const uint64_t pfin = p - (uint64_t)rem;
+          const uint64_t line = pfin / kPosPerLine;
+          const uint32_t slot = (uint32_t)(pfin - line * kPosPerLine);
+          const char* lb = reinterpret_cast<const char*>(ix.pos_lines + line);
+          const uint32_t ob = 32u + 5u * slot;
+          pc = reinterpret_cast<const u64_a4*>(lb + (ob & ~3u));
+          sh = ob & 3u;
           tally += 1;
+          if (slot + rem <= 128u) {  // the line holds the text too
+            const uint32_t off = 128u - (slot + rem);
+            pa = reinterpret_cast<const uint4*>(lb) + (off >> 6);
+            pb = pa + 1;
+            o = off & 63u;
+            from_text = false;
+          }
         } else {
           pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
           free_r = false;
         }
+        if (from_text) {
+          const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
+          pa = t4;
+          pb = t4 + 1;
+          const uint64_t x1 = x0 + ((piece_end < L ? piece_end : L) - j) - 1;  // last base compared
+          tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;                     // 512 bases per 128-byte line
+        }
+        aux = (aux & ~0xffu) | o | (sh << 6);
         break;
       }
-      case S_MISROW:
-        pc = ix.row_tab + p;
+      case S_MISROW: {
+        const uint64_t line = p / kPosPerLine;
+        const uint32_t ob = 32u + 5u * (uint32_t)(p - line * kPosPerLine);
+        pc = reinterpret_cast<const u64_a4*>(reinterpret_cast<const char*>(ix.pos_lines + line) + (ob & ~3u));
+        aux = (aux & ~0xffu) | ((ob & 3u) << 6);
         tally += 1;
         break;
+      }
       case S_REFETCH:
         pr = reinterpret_cast<const uint4*>(rp) + (j >> 6);
         free_r = false;
@@ -507,9 +531,8 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       }
       case S_CMP: {
         // bases [j, min(L, end of the read's 64-base piece)) against the text at x0.. (device_index.hip: text-jump)
-        const uint64_t x0 = ix.n - 1 - p;
         uint64_t t0, t1, r0, r1;
-        sm_funnel128(u64_of(va.x, va.y), u64_of(va.z, va.w), u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), (uint32_t)(x0 & 63), t0, t1);
+        sm_funnel128(u64_of(va.x, va.y), u64_of(va.z, va.w), u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), aux & 63u, t0, t1);
         sm_funnel128(w_lo, w_hi, 0, 0, j & 63u, r0, r1);
         const uint32_t piece_end = (j | 63u) + 1u;
         const uint32_t stop = piece_end < L ? piece_end : L;
@@ -526,7 +549,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         if (t < nb) {
           st = S_MISROW;  // the chain dies at base j: exec_exact_match on the row of text position p
         } else if (j == L) {
-          lo = vc;  // row_tab[p]: the row the chain ends on
+          lo = (vc >> (8u * ((aux >> 6) & 3u))) & kPosMask;  // the row the chain ends on (row of position p)
           hi = lo + 1;
           aux |= A_LOCATED;  // the position is p
           finish = true;
@@ -537,7 +560,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         break;
       }
       case S_MISROW: {
-        lo = vc;
+        lo = (vc >> (8u * ((aux >> 6) & 3u))) & kPosMask;
         hi = lo + 1;
         const uint32_t c = ((uint32_t)((j & 32u ? w_hi : w_lo) >> (2 * (j & 31u))) & 3u) ^ 3u;
         aux = (aux & ~0x3ffu) | c | (M_DEAD << 8);
