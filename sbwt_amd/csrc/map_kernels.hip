@@ -159,6 +159,7 @@ struct sbwt_ctx {
   uint32_t grid_sort = 0;                     // ... of k_multi_sort
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
+  size_t sort_lds_bytes = 0;                  // filter tables of k_multi_sort in LDS (0: they stay in global memory)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[3] = {0, 0, 0};
   uint64_t last_stats[4] = {0, 0, 0, 0};
@@ -202,7 +203,8 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes + ring_bytes);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, ring_bytes);
     int sort_per_cu = 0;
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, 0);
+    if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys) c->sort_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, c->sort_lds_bytes);
     c->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
     if (e == hipSuccess) {
       c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
@@ -336,8 +338,9 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     ms.overflow = &c->d_ctr->overflow;
     ms.dfs_queue = c->d_dfs_queue;
     ms.dfs_count = &c->d_ctr->dfs_count;
-    k_multi_sort<64><<<c->grid_sort, 256, 0, c->stream>>>(d, ms);
-    k_multi_sort<256><<<c->grid_sort, 256, 0, c->stream>>>(d, ms);
+    ms.lds_tables = c->sort_lds_bytes ? 1u : 0u;
+    k_multi_sort<64><<<c->grid_sort, 256, c->sort_lds_bytes, c->stream>>>(d, ms);
+    k_multi_sort<256><<<c->grid_sort, 256, c->sort_lds_bytes, c->stream>>>(d, ms);
     SBWT_LAUNCHED();
     k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(d, a, c->d_stacks, c->multi_lanes, c->d_dfs_queue,
                                                          &c->d_ctr->dfs_count);

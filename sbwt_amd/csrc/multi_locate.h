@@ -34,6 +34,7 @@ struct MultiSortArgs {
   uint64_t chunk;
   const unsigned long long* queue_count; // total number of queued reads (k_multi_plan)
   const unsigned int* overflow;          // set by k_multi_plan when the hit slots do not fit hits_cap
+  uint32_t lds_tables;                   // the launch carries (n_chr + 2 n_npos) * 8 bytes of dynamic LDS for the filter tables
   uint32_t* dfs_queue;                   // reads this kernel hands on to k_multi
   unsigned long long* dfs_count;
 };
@@ -98,128 +99,251 @@ __device__ __forceinline__ void team_sync() {
   }
 }
 
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, uint32_t lane_mask) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, (int)lane_mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)lane_mask);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Bitonic sort of N = T * E words held E per thread (element tid * E + k in v[k]): strides below E stay inside the
+// thread, strides below 64 * E go through lane shuffles, only the widest ones (workgroup teams) through LDS.
+template <int T, int E, typename Less>
+__device__ __forceinline__ void team_bitonic(uint64_t (&v)[4], uint32_t tid, uint64_t* xch, Less less) {
+  constexpr uint32_t N = (uint32_t)T * E;
+  for (uint32_t size = 2; size <= N; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride < (uint32_t)E) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+          if ((uint32_t)k & stride) continue;
+          const int k2 = k + (int)stride;
+          if (k2 >= E) continue;
+          const bool up = ((tid * E + (uint32_t)k) & size) == 0;
+          const uint64_t x = v[k], y = v[k2];
+          if (less(y, x) == up) { v[k] = y; v[k2] = x; }
+        }
+      } else {
+        const uint32_t tmask = stride / (uint32_t)E;  // partner thread = tid ^ tmask
+        const bool lower = (tid & tmask) == 0;
+        uint64_t other[4];
+        if (tmask < 64u) {
+#pragma unroll
+          for (int k = 0; k < E; ++k) other[k] = shfl_xor64(v[k], tmask);
+        } else {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < E; ++k) xch[tid * E + (uint32_t)k] = v[k];
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < E; ++k) other[k] = xch[(tid ^ tmask) * E + (uint32_t)k];
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+          const bool up = ((tid * E + (uint32_t)k) & size) == 0;
+          // the lower element of the pair keeps the smaller word when the pair sorts upwards
+          const bool take_small = lower == up;
+          const bool other_small = less(other[k], v[k]);
+          if (other_small == take_small) v[k] = other[k];
+        }
+      }
+    }
+  }
+}
+
+// hit of one row as it waits in LDS for its place in the emission order:
+// pos0 (40 bits) | chr_id << 40 (16 bits) | is_rc << 56 | passed the filters << 57 | t << 58 (6 bits)
+constexpr uint64_t kPayOk = 1ull << 57;
+
 template <int T>
 __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;  // rows a team can sort
-  __shared__ uint64_t s_k0[kSortMax], s_k1[kSortMax];
-  __shared__ uint32_t s_k2[kSortMax];
+  // what is sorted is one 64-bit word per row: the first 24 prepended bases (48 bits) over the row's offset in
+  // the interval (16 bits).  Rows whose first 24 bases agree are compared in full through the offset (rare).
+  __shared__ uint64_t s_k0[kSortMax], s_k1[kSortMax], s_key[kSortMax], s_pay[kSortMax];
+  __shared__ uint32_t s_list_all[256];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_bad_all[4];
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];  // (n_chr + 2 n_npos) words when a.lds_tables
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
+  // push_position tables: LDS copies when they fit
+  const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
+  if (a.lds_tables) {
+    uint64_t* s_chr = s_tab;
+    uint64_t* s_nk = s_chr + ix.n_chr;
+    uint64_t* s_nv = s_nk + ix.n_npos;
+    for (uint32_t k = threadIdx.x; k < ix.n_chr; k += blockDim.x) s_chr[k] = ix.chr_start[k];
+    for (uint32_t k = threadIdx.x; k < ix.n_npos; k += blockDim.x) { s_nk[k] = ix.npos_key[k]; s_nv[k] = ix.npos_val[k]; }
+    __syncthreads();
+    t_chr = s_chr; t_nk = s_nk; t_nv = s_nv;
+  }
   const uint32_t team = threadIdx.x / T, tid = threadIdx.x % T;
+  const uint32_t lane = threadIdx.x & 63;
   uint64_t* k0 = s_k0 + team * kCap;
   uint64_t* k1 = s_k1 + team * kCap;
-  uint32_t* k2 = s_k2 + team * kCap;
+  uint64_t* key = s_key + team * kCap;
+  uint64_t* pay = s_pay + team * kCap;
+  uint32_t* list = s_list_all + team * T;
   uint32_t* s_bad = s_bad_all + team;
   const uint64_t m_text = ix.n - 1;
+  const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
+  // full order of two rows given their offsets: prepended string (zero padded), its length, the offset
+  auto row_less = [&](uint32_t ia, uint32_t ib) -> bool {
+    const uint64_t a0 = k0[ia], b0 = k0[ib];
+    if (a0 != b0) return a0 < b0;
+    const uint64_t a1 = k1[ia], b1 = k1[ib];
+    if (a1 != b1) return a1 < b1;
+    const uint32_t ta = (uint32_t)(pay[ia] >> 58), tb = (uint32_t)(pay[ib] >> 58);
+    if (ta != tb) return ta < tb;
+    return ia < ib;
+  };
   // teams stride over the waves of the search kernel; each wave queued its reads at queue[w * chunk ..)
   for (uint32_t w = blockIdx.x * kTeams + team; w < a.n_waves; w += gridDim.x * kTeams) {
     const WaveInfo wi = a.wave_info[w];
-    for (uint32_t qi = 0; qi < wi.count; ++qi) {
-      const uint32_t r = a.queue[(uint64_t)w * a.chunk + qi];
-      sbwt_read_result res = a.results[r];
-      const uint64_t lo = res.sa_lo, m = res.sa_hi - res.sa_lo;
-      // which launch takes this read
-      if (T == 64 ? m > kCap : m <= kSortMax / 4) continue;
-      res.first_hit += a.n_reads + wi.slots;  // wave-relative until now
-      if (tid == 0) *s_bad = (m > kCap || ix.interval > 64) ? 1u : 0u;
-      team_sync<T>();
-      uint32_t N = 64;
-      while (N < m && N < kCap) N <<= 1;
-      if (!*s_bad) {
-        // keys: the prepended string of every row (first base most significant, zero padded), then its length
-        // and the row's offset in the interval
-        for (uint32_t i = tid; i < N; i += T) {
-          uint64_t h0 = ~0ull, h1 = ~0ull;
-          uint32_t h2 = ~0u;
-          if (i < m) {
-            const uint64_t e = ix.sa_full[lo + i];
-            const uint64_t p = e & kPosMask, run = e >> kPosBits;
-            const uint32_t t = (uint32_t)(p % ix.interval);
-            const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
-            if (e == kNoPosition || run < need) {
-              *s_bad = 1u;  // benign race: every writer stores 1
-            } else {
-              // text[p - 1 - k] = 3 - textrc[x0 + k]
-              const uint64_t x0 = m_text - p;
-              const uint64_t wi0 = x0 >> 4;
-              const uint32_t sh = 2u * (uint32_t)(x0 & 15);
-              const uint32_t* tx = ix.textrc + wi0;
-              const uint64_t w0 = tx[0] | ((uint64_t)tx[1] << 32), w1 = tx[2] | ((uint64_t)tx[3] << 32), w2 = tx[4];
-              uint64_t c0 = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
-              uint64_t c1 = sh ? ((w1 >> sh) | (w2 << (64 - sh))) : w1;
-              c0 = ~c0;
-              c1 = ~c1;
-              if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; c1 = 0; }
-              else if (t < 64u) c1 &= t > 32u ? ((1ull << (2 * (t - 32u))) - 1ull) : 0ull;
-              h0 = rev_bases(c0);
-              h1 = rev_bases(c1);
-              h2 = (t << 16) | i;
-            }
-          }
-          k0[i] = h0; k1[i] = h1; k2[i] = h2;
-        }
+    for (uint32_t q0 = 0; q0 < wi.count; q0 += T) {
+      // the team looks at T queue entries at once and keeps those this launch takes
+      uint32_t my_r = 0;
+      bool mine = false;
+      if (q0 + tid < wi.count) {
+        my_r = a.queue[(uint64_t)w * a.chunk + q0 + tid];
+        const uint64_t m = a.results[my_r].sa_hi - a.results[my_r].sa_lo;
+        mine = T == 64 ? m <= kCap : m > kSortMax / 4;
       }
-      team_sync<T>();
-      if (*s_bad) {
-        if (tid == 0) {
-          a.results[r].first_hit = res.first_hit;
-          a.dfs_queue[atomicAdd(a.dfs_count, 1ull)] = r;
-        }
-        team_sync<T>();
-        continue;
-      }
-      // bitonic sort of N keys
-      for (uint32_t size = 2; size <= N; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-          for (uint32_t t = tid; t < (N >> 1); t += T) {
-            const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
-            const uint32_t j = i + stride;
-            const bool up = (i & size) == 0;
-            const uint64_t a0 = k0[i], a1 = k1[i], b0 = k0[j], b1 = k1[j];
-            const uint32_t a2 = k2[i], b2 = k2[j];
-            if (key_less(b0, b1, b2, a0, a1, a2) == up) {
-              k0[i] = b0; k1[i] = b1; k2[i] = b2;
-              k0[j] = a0; k1[j] = a1; k2[j] = a2;
-            }
-          }
-          team_sync<T>();
-        }
-      }
-      // filter in emission order, compact, write
-      const uint32_t L = a.lens[r];
-      sbwt_hit* out = a.hits + res.first_hit;
-      uint32_t base = 0;
-      for (uint32_t c = 0; c < m; c += T) {
-        const uint32_t k = c + tid;
-        bool ok = false;
-        sbwt_hit h;
-        if (k < m) {
-          const uint64_t e = ix.sa_full[lo + (k2[k] & 0xffffu)];
-          ok = push_position_lane(ix, e & kPosMask, L, a.strand, &h);
-        }
-        const uint64_t bal = __ballot(ok);
-        const uint32_t lane = threadIdx.x & 63;
+      uint32_t n_list;
+      {
+        const uint64_t bal = __ballot(mine);
+        uint32_t off = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         if (T == 256) {
           const uint32_t wave = threadIdx.x >> 6;
+          __syncthreads();  // the previous batch is done with list and s_scan_all
           if (lane == 0) s_scan_all[wave] = (uint32_t)__popcll(bal);
           __syncthreads();
-          uint32_t off = base;
           for (uint32_t v = 0; v < wave; ++v) off += s_scan_all[v];
-          if (ok) out[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = h;
-          base += s_scan_all[0] + s_scan_all[1] + s_scan_all[2] + s_scan_all[3];
-          __syncthreads();
+          n_list = s_scan_all[0] + s_scan_all[1] + s_scan_all[2] + s_scan_all[3];
         } else {
-          if (ok) out[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = h;
-          base += (uint32_t)__popcll(bal);
+          n_list = (uint32_t)__popcll(bal);
         }
-      }
-      if (tid == 0) {
-        a.results[r].first_hit = res.first_hit;
-        a.results[r].nh = (int32_t)base;
+        if (mine) list[off] = my_r;
       }
       team_sync<T>();
+      for (uint32_t li = 0; li < n_list; ++li) {
+        const uint32_t r = list[li];
+        sbwt_read_result res = a.results[r];
+        const uint64_t lo = res.sa_lo, m = res.sa_hi - res.sa_lo;
+        const uint32_t L = a.lens[r];
+        res.first_hit += a.n_reads + wi.slots;  // wave-relative until now
+        if (tid == 0) *s_bad = (m > kCap || no_sort_path) ? 1u : 0u;
+        team_sync<T>();
+        uint32_t N = 64;
+        while (N < m && N < kCap) N <<= 1;
+        if (!*s_bad) {
+          // up to four rows per thread, phase by phase, so that the loads of all of them are in flight together
+          uint64_t e4[4];
+          uint32_t tw[4][5];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t i = tid + (uint32_t)kk * T;
+            e4[kk] = i < m ? ix.sa_full[lo + i] : kNoPosition;
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const uint64_t p = e4[kk] & kPosMask;
+            // text[p - 1 - k] = 3 - textrc[x0 + k]; a row without a position reads the start of the text
+            const uint64_t x0 = e4[kk] == kNoPosition || p > m_text ? 0 : m_text - p;
+            const uint32_t* tx = ix.textrc + (x0 >> 4);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) tw[kk][q] = tx[q];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t i = tid + (uint32_t)kk * T;
+            if (i >= N) continue;
+            uint64_t h0 = ~0ull, h1 = ~0ull, py = 63ull << 58;
+            if (i < m) {
+              const uint64_t e = e4[kk];
+              const uint64_t p = e & kPosMask, run = e >> kPosBits;
+              const uint32_t t = (uint32_t)(p % ix.interval);
+              const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
+              if (e == kNoPosition || run < need) {
+                *s_bad = 1u;  // benign race: every writer stores 1
+              } else {
+                const uint64_t x0 = m_text - p;
+                const uint32_t sh = 2u * (uint32_t)(x0 & 15);
+                const uint64_t w0 = tw[kk][0] | ((uint64_t)tw[kk][1] << 32), w1 = tw[kk][2] | ((uint64_t)tw[kk][3] << 32), w2 = tw[kk][4];
+                sbwt_hit h;
+                const bool ok = push_position_keys(ix, t_chr, t_nk, t_nv, p, L, a.strand, &h);  // searcher.hpp:504-539
+                uint64_t c0 = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+                uint64_t c1 = sh ? ((w1 >> sh) | (w2 << (64 - sh))) : w1;
+                c0 = ~c0;
+                c1 = ~c1;
+                if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; c1 = 0; }
+                else if (t < 64u) c1 &= t > 32u ? ((1ull << (2 * (t - 32u))) - 1ull) : 0ull;
+                h0 = rev_bases(c0);
+                h1 = rev_bases(c1);
+                py = ((uint64_t)t << 58);
+                if (ok) py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+              }
+            }
+            k0[i] = h0; k1[i] = h1; pay[i] = py;
+            key[i] = (h0 & ~0xFFFFull) | i;  // padding rows: all ones, behind every real row
+          }
+        }
+        team_sync<T>();
+        if (*s_bad) {
+          if (tid == 0) {
+            a.results[r].first_hit = res.first_hit;
+            a.dfs_queue[atomicAdd(a.dfs_count, 1ull)] = r;
+          }
+          team_sync<T>();
+          continue;
+        }
+        // bitonic sort of the N words in LDS; the full keys are looked up only for words whose first 24 bases agree
+        for (uint32_t size = 2; size <= N; size <<= 1) {
+          for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (N >> 1); t += T) {
+              const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
+              const uint32_t j = i + stride;
+              const bool up = (i & size) == 0;
+              const uint64_t ka = key[i], kb = key[j];
+              bool b_less = kb < ka;
+              if (((ka ^ kb) >> 16) == 0) b_less = row_less((uint32_t)kb & 0xFFFFu, (uint32_t)ka & 0xFFFFu);
+              if (b_less == up) { key[i] = kb; key[j] = ka; }
+            }
+            team_sync<T>();
+          }
+        }
+        // rows in emission order: compact those that passed the filters, write
+        sbwt_hit* out = a.hits + res.first_hit;
+        uint32_t base = 0;
+        for (uint32_t c = 0; c < m; c += T) {
+          const uint32_t k = c + tid;
+          uint64_t py = 0;
+          if (k < m) py = pay[(uint32_t)key[k] & 0xFFFFu];
+          const bool ok = (py & kPayOk) != 0;
+          sbwt_hit h;
+          h.pos0 = py & kPosMask;
+          h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
+          h.is_rc = (uint32_t)(py >> 56) & 1u;
+          const uint64_t bal = __ballot(ok);
+          if (T == 256) {
+            const uint32_t wave = threadIdx.x >> 6;
+            if (lane == 0) s_scan_all[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t off = base;
+            for (uint32_t v = 0; v < wave; ++v) off += s_scan_all[v];
+            if (ok) out[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = h;
+            base += s_scan_all[0] + s_scan_all[1] + s_scan_all[2] + s_scan_all[3];
+            __syncthreads();
+          } else {
+            if (ok) out[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = h;
+            base += (uint32_t)__popcll(bal);
+          }
+        }
+        if (tid == 0) {
+          a.results[r].first_hit = res.first_hit;
+          a.results[r].nh = (int32_t)base;
+        }
+        team_sync<T>();
+      }
     }
   }
 }
