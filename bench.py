@@ -251,17 +251,24 @@ def main():
     achieved = algo_bytes / (search_ms * 1e-3) / 1e9
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/profile_final.sh from PMC passes
+    requests = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from the PMC passes of tools/profile_final.sh
     if os.path.exists(tpath):
         t = json.load(open(tpath))
         if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9:
             traffic = t.get("traffic_GB_per_launch")
+            if t.get("TCC_EA0_RDREQ") and t.get("TCC_EA0_WRREQ"):
+                requests = t["TCC_EA0_RDREQ"] + t["TCC_EA0_WRREQ"]
     roofline = {"bound": "hbm", "kernel": "k_search_sm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/traffic.json)",
                 "launch_ms": round(search_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
                 "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
                 "index_lines_per_s_G": round(accesses / (search_ms * 1e-3) / 1e9, 2),
                 "gather_roofline_lines_per_s_G": 47.0,
+                # HBM requests per launch (PMC, profiles/traffic.json) over this run's launch time, against the
+                # measured random-access roofline of 47 G requests/s (profiles/r1/gather_probe*.txt)
+                "hbm_requests_per_s_G": round(requests / (search_ms * 1e-3) / 1e9, 2) if requests else None,
+                "gather_roofline_frac": round(requests / (search_ms * 1e-3) / 47e9, 3) if requests else None,
                 "survey_formula_GBps": round(survey_per_read * n_reads / (search_ms * 1e-3) / 1e9, 1)}
 
     cpu = None
