@@ -4,7 +4,7 @@
 // or more two-base steps, memoised locate, text comparison + final row), and reads differ in chain length.  A
 // kernel that walks "one read per lane, phase by phase" leaves lanes idle whenever their neighbours need a step
 // more.  Here every lane runs its own chain: each loop iteration a lane issues the loads of its CURRENT state
-// through a fixed set of load slots (two 16-byte, one 16-byte read piece, two 8-byte, one 4-byte), the wave waits
+// through a fixed set of load slots (two 16-byte, one 16-byte read piece, four 8-byte, one 4-byte), the wave waits
 // ONCE, every lane consumes its slots and moves to its next state, and a lane whose read is finished takes the
 // next read of the wave's range.  All memory waits of all reads of the wave overlap, whatever their state.
 //
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
 
     // ---- issue: every lane points the slots it needs at its own addresses
     // (a slot a lane does not need points at the start of the batch: one cached line for the whole wave; the
-    // loads are unconditional so that all six are in flight before the single wait)
+    // loads are unconditional so that all eight are in flight before the single wait)
     const uint4* const idle16 = reinterpret_cast<const uint4*>(a.packed);
     const uint64_t* const idle8 = reinterpret_cast<const uint64_t*>(a.packed);
     const uint4* pa = idle16;    // 16 B
