@@ -92,7 +92,7 @@ def plant_repeats(torch, dev, codes, g, seed, n_families=2000, max_copies=5000):
     return slots
 
 
-def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=None, mutate=0.0):
+def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=None, mutate=0.0, origins=None):
     """n_reads error-free reads, strand uniform -> packed int32 [n_reads, wpr], lens int32.  Length L, or uniform
     in min_len..L; with `slots`, half of the reads start inside a planted repeat"""
     gen = torch.Generator(device=dev)
@@ -110,6 +110,8 @@ def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=
             use = torch.randint(0, 2, (b - a,), device=dev, generator=gen).bool()
             pos = torch.where(use, pick, pos)
         rev = torch.randint(0, 2, (b - a,), device=dev, generator=gen, dtype=torch.int64).bool()
+        if origins is not None:
+            origins.append((pos, rev))
         bases = codes[(pos[:, None] + ar[None, :])].to(torch.int32)          # forward strand
         rc = 3 - bases.flip(1)
         bases = torch.where(rev[:, None], rc, bases)
@@ -129,6 +131,41 @@ def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=
             buf *= (torch.arange(wpr * 16, device=dev)[None, :] < ln[:, None]).to(torch.int32)
         packed[a:b] = (buf.view(b - a, wpr, 16) << shifts).sum(dim=2, dtype=torch.int32)
     return packed, lens
+
+
+def origin_check(torch, dev, results, hits, origins, L, chr_start, npos_key, npos_val):
+    """Full-size property of the error-free workload (no oracle needed): a read cut from forward offset `pos` must
+    come back with exactly that origin -- chromosome, 0-based position with the N offset added, strand flag
+    (searcher.hpp:504-539: a forward read is found in the reverse-complement half, isRC) -- at hits[its own
+    index], unless its first and last base lie in different chromosomes or N-free stretches (then NH = 0)."""
+    cs = torch.tensor(chr_start, dtype=torch.int64, device=dev)
+    nk = torch.tensor(npos_key, dtype=torch.int64, device=dev)
+    nv = torch.tensor(npos_val, dtype=torch.int64, device=dev)
+    bounds = torch.unique(torch.cat([cs, nk]))
+    res = results.view(torch.int64).view(-1, 4)
+    hit = hits.view(torch.int64).view(-1, 2)
+    bad = 0
+    spanning = 0
+    a = 0
+    for pos, rev in origins:
+        b = a + pos.numel()
+        seg0 = torch.searchsorted(bounds, pos, right=True)
+        seg1 = torch.searchsorted(bounds, pos + (L - 1), right=True)
+        span = seg0 != seg1
+        c = torch.searchsorted(cs, pos, right=True) - 1
+        k = torch.searchsorted(nk, pos, right=True) - 1
+        pos0 = pos - cs[c] + nv[k]
+        word = c | ((~rev).to(torch.int64) << 32)          # chr_id | is_rc << 32
+        r = res[a:b]
+        nh = r[:, 3] & 0xFFFFFFFF
+        idx = torch.arange(a, b, device=dev, dtype=torch.int64)
+        h = hit[a:b]
+        ok_hit = (nh == 1) & (r[:, 1] - r[:, 0] == 1) & (r[:, 2] == idx) & (h[:, 0] == pos0) & (h[:, 1] == word)
+        ok = torch.where(span, nh == 0, ok_hit)
+        bad += int((~ok).sum())
+        spanning += int(span.sum())
+        a = b
+    return {"reads": a, "mismatches": bad, "boundary_spanning_reads": spanning}
 
 
 def unpack_reads(packed_np, lens_np):
@@ -198,7 +235,10 @@ def main():
     wpr = sbwt_amd.words_per_read(L)
     n_reads = args.reads
     t0 = time.time()
-    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots, mutate=args.mutate)
+    plain = args.min_len is None and slots is None and args.mutate == 0.0
+    origins = [] if (plain and rank == 0) else None
+    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots,
+                              mutate=args.mutate, origins=origins)
     del codes
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
@@ -233,6 +273,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    origin = None
+    if origins is not None:
+        origin = origin_check(torch, dev, results, hits, origins, L, chr_start, npos_key, npos_val)
+        del origins
     value = world * n_reads * args.steps / elapsed
     search_ms = float(np.mean([k[1] for k in kernel_ms]))
     multi_ms = float(np.mean([k[2] for k in kernel_ms]))
@@ -334,7 +378,7 @@ def main():
         "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "hits": int(n_hits),
                    "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
                    "setup_s": {"genome": round(t_genome, 1), "index_build": round(t_index, 1), "reads": round(t_reads, 1)},
-                   "parity_vs_oracle": parity},
+                   "parity_vs_oracle": parity, "origin_check": origin},
     }
     print(json.dumps(line), flush=True)
     if dist is not None:
