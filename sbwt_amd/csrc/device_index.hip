@@ -539,6 +539,56 @@ __global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, 
   tab[v] = entry;
 }
 
+// ---- hash_tab: located prefixes of order K (device_layout.h) ----------------------------------------------
+// One thread per row: the K-mer in front of the row's text position, the upstream steps for that K-mer (exactly as
+// k_kmer_table runs them), and an entry only when they end on this very row, alone.
+__global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets,
+                                                    uint32_t tag_bits, unsigned long long* __restrict__ counts) {
+  const uint64_t i = global_thread();
+  uint32_t outcome = 0;  // 1 stored, 2 left out
+  const uint64_t e = i < ix.n ? ix.sa_full[i] : kNoPosition;
+  const uint64_t p = e & kPosMask, run = e >> kPosBits;
+  const uint64_t m = ix.n - 1;
+  if (e != kNoPosition && run >= 1 && p + K <= m) {  // K real bases behind the position
+    // digit t of v = complemented code of read[t] = 3 - textrc[x0 + t], x0 = m - p - K
+    const uint64_t x0 = m - p - K;
+    const uint32_t* tx = ix.textrc + (x0 >> 4);
+    const uint32_t sh = 2u * (uint32_t)(x0 & 15);
+    const uint64_t w0 = tx[0] | ((uint64_t)tx[1] << 32), w1 = tx[2];
+    const uint64_t bits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+    const uint64_t v = (~bits) & ((1ull << (2 * K)) - 1ull);
+    const uint32_t kmer = (uint32_t)v & 0xFFFFFFu;
+    uint64_t lo = ix.c_functions[kmer], hi = ix.c_functions[kmer + 1];
+    bool alive = lo < hi;
+    uint32_t t = kKmer;
+    for (; alive && t + 2 <= K; t += 2)
+      alive = step_two_bases(ix, ((uint32_t)(v >> (2 * t)) & 15u) ^ 15u, lo, hi);
+    if (alive && t < K) {
+      const uint32_t c = (uint32_t)(v >> (2 * t)) & 3u;
+      const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
+      lo = l1;
+      hi = h1;
+      alive = lo < hi;
+    }
+    if (alive && hi - lo == 1 && lo == i) {
+      const uint64_t vv = hash_mix(v, K);
+      const uint64_t b = __umul64hi(vv << (64 - 2 * K), n_buckets);
+      const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
+      const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | (vv & ((1ull << tag_bits) - 1ull));
+      unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + b * kHashSlots;
+      outcome = 2;  // bucket full: this K-mer stays with the fallback path
+      for (uint32_t s = 0; s < kHashSlots; ++s)
+        if (atomicCAS(&bk[s], ~0ull, (unsigned long long)slot) == ~0ull) { outcome = 1; break; }
+    }
+  }
+  // statistics: one pair of atomics per wave
+  const uint64_t stored = __ballot(outcome == 1), left = __ballot(outcome == 2);
+  if ((threadIdx.x & 63) == 0) {
+    if (stored) atomicAdd(&counts[0], (unsigned long long)__popcll(stored));
+    if (left) atomicAdd(&counts[1], (unsigned long long)__popcll(left));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t items, uint32_t per_block) { return grid_items(items, per_block); }
 
@@ -684,9 +734,30 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     size_t free_b = 0, total_b = 0;
     SBWT_HIP(hipMemGetInfo(&free_b, &total_b));
     constexpr uint64_t kKmerHeadroom = 24ull << 30;
-    for (uint32_t k = kKmer + 1; k <= kMaxKmerOrder; ++k) {
+    // hash table of located order-20 prefixes (device_layout.h): 1.6 slots per suffix, on indexes of 2^24 suffixes
+    // or more when it fits next to an order-16 direct table; SBWT_HASH_ORDER overrides (0 = none)
+    uint32_t H = raw.n >= (1ull << 24) ? 20u : 0u;
+    if (const char* e = getenv("SBWT_HASH_ORDER")) {
+      const int want = atoi(e);
+      if (want == 0 || (want > kKmer && want <= (int)kHashMaxOrder)) H = (uint32_t)want;
+    }
+    uint64_t n_buckets = 0;
+    uint32_t tag_bits = 0;
+    if (H) {
+      n_buckets = (raw.n * 8 / 5 + kHashSlots - 1) / kHashSlots;  // 1.6 slots per suffix
+      // a tag of at most 16 bits must tell the values of one bucket apart: 2^(tag_bits - 1) >= 4^H / n_buckets
+      if (2 * H > 15 && n_buckets < (1ull << (2 * H - 15))) n_buckets = 1ull << (2 * H - 15);
+      tag_bits = 1;
+      while ((n_buckets << (tag_bits - 1)) < (1ull << (2 * H))) ++tag_bits;
+      const uint64_t direct16 = raw.n >= (1ull << 28) ? (8ull << 32) : 0;  // what an order-16 direct table takes
+      if (n_buckets * (8 * kHashSlots) + direct16 + kKmerHeadroom > (uint64_t)free_b) H = 0;
+      if (raw.n + 256 >= kPosMask) H = 0;  // the high word of a slot must never be all ones (that marks an empty slot)
+    }
+    const uint32_t max_direct = H ? 16u : kMaxKmerOrder;
+    for (uint32_t k = kKmer + 1; k <= max_direct; ++k) {
       const uint64_t entries = 1ull << (2 * k);
-      if (entries > 16 * raw.n || entries * 8 + kKmerHeadroom > (uint64_t)free_b) break;
+      const uint64_t other = H ? n_buckets * (8 * kHashSlots) : 0;
+      if (entries > 16 * raw.n || entries * 8 + other + kKmerHeadroom > (uint64_t)free_b) break;
       K = k;
     }
     if (const char* e = getenv("SBWT_KMER_ORDER")) {
@@ -694,8 +765,32 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       if (want >= kKmer && want <= (int)kMaxKmerOrder) K = (uint32_t)want;
     }
     if (getenv("SBWT_DEBUG"))
-      fprintf(stderr, "[sbwt debug] device memory: %.1f GB free of %.1f GB before the prefix table; order %u (%.1f GB)\n",
-              free_b / 1e9, total_b / 1e9, K, K > (uint32_t)kKmer ? 8.0 * (double)(1ull << (2 * K)) / 1e9 : 0.0);
+      fprintf(stderr, "[sbwt debug] device memory: %.1f GB free of %.1f GB before the prefix tables; direct order %u (%.1f GB), hash order %u (%.1f GB, %u tag bits)\n",
+              free_b / 1e9, total_b / 1e9, K, K > (uint32_t)kKmer ? 8.0 * (double)(1ull << (2 * K)) / 1e9 : 0.0, H,
+              (double)n_buckets * (8 * kHashSlots) / 1e9, tag_bits);
+    d.hash_tab = nullptr;
+    d.hash_order = 0;
+    d.hash_buckets = 0;
+    d.hash_tag_bits = 0;
+    if (H) {
+      uint64_t* htab = nullptr;
+      unsigned long long* d_counts = nullptr;
+      if (int rc = dev_alloc(ix, &htab, n_buckets * kHashSlots)) return rc;
+      SBWT_HIP(hipMalloc(&d_counts, 16));
+      SBWT_HIP(hipMemset(d_counts, 0, 16));
+      SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (8 * kHashSlots)));
+      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, d_counts);
+      SBWT_LAUNCHED();
+      unsigned long long h_counts[2];
+      SBWT_HIP(hipMemcpy(h_counts, d_counts, 16, hipMemcpyDeviceToHost));
+      hipFree(d_counts);
+      if (getenv("SBWT_DEBUG"))
+        fprintf(stderr, "[sbwt debug] hash table: %llu prefixes stored, %llu left out (bucket full)\n", h_counts[0], h_counts[1]);
+      d.hash_tab = htab;
+      d.hash_order = H;
+      d.hash_buckets = n_buckets;
+      d.hash_tag_bits = tag_bits;
+    }
     d.kmer_order = K;
     d.kmer_tab = nullptr;
     if (K > (uint32_t)kKmer) {

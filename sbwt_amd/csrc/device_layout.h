@@ -50,6 +50,7 @@ struct alignas(128) PosLine {
 };
 static_assert(sizeof(PosLine) == 128, "PosLine is one 128-byte granule");
 typedef uint64_t u64_a4 __attribute__((aligned(4)));  // 8-byte load from a 4-byte aligned address
+struct __attribute__((aligned(8))) uint4_a8 { uint32_t x, y, z, w; };  // 16-byte load from an 8-byte aligned address
 
 constexpr uint64_t kNoPosition = ~0ull;  // sa_full sentinel: the upstream unique-hit walk reports nothing
 // sa_full entry = text position (low 40 bits) | run (high 24 bits, saturating): the number of consecutive text
@@ -61,6 +62,18 @@ constexpr uint32_t kMaxKmerOrder = 17;  // widest memoised search prefix (4^17 e
 // run (23 bits, saturating) -- the search goes straight to the text comparison, without the sa_full access
 constexpr uint64_t kKmerLocated = 1ull << 63;
 constexpr uint64_t kKmerRunMax = (1ull << 23) - 1;
+// hash_tab: located search prefixes of a LONGER order than a direct table can hold (default 20 bases).  Buckets of
+// four 8-byte slots (32 B: two 16-byte loads; the search kernel is bound by load requests as much as by lines); a slot = text position << 24 | run (saturating) << tag_bits | tag, all ones = empty.
+// A K-mer v (complemented read codes, as for kmer_tab) is mixed by an odd multiplier modulo 4^K (a bijection), the
+// bucket is the mixed value scaled to the bucket count (so the values of one bucket form an interval shorter than
+// 2^(tag_bits - 1)) and the tag its low tag_bits bits: bucket and tag identify v exactly.  Only K-mers whose
+// upstream search interval is ONE located row are in the table (and of those, the few that found their bucket full
+// are left out): a miss falls back to kmer_tab / c_functions, so the table never changes a result.
+constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
+constexpr uint32_t kHashSlots = 4;
+constexpr uint32_t kHashMaxOrder = 28;
+__host__ __device__ inline uint64_t hash_mix(uint64_t v, uint32_t order) { return (v * kHashMul) & ((1ull << (2 * order)) - 1ull); }
+
 constexpr int kPosBits = 40;
 constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
 constexpr uint64_t kRunMax = (1ull << (64 - kPosBits)) - 1;
@@ -86,6 +99,7 @@ struct DeviceIndex {
   // memoised search prefix: entry v = interval after init_exact_match + exec_exact_match over the first kmer_order
   // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised; kKmerLocated form below)
   const uint64_t* kmer_tab; uint32_t kmer_order;  // kmer_order = 12: no table
+  const uint64_t* hash_tab; uint64_t hash_buckets; uint32_t hash_order; uint32_t hash_tag_bits;  // hash_order = 0: none
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;

@@ -124,11 +124,13 @@ constexpr uint32_t A_NOPOS = 1u << 18;    // the upstream locate reports nothing
 constexpr uint32_t A_PIECE = 1u << 19;    // w holds the read piece j is in (set by S_REFETCH)
 constexpr uint32_t A_CUR_W = 1u << 20;    // S_START: the read's record was prefetched (w_lo, w_hi, L)
 constexpr uint32_t A_CUR_K = 1u << 21;    // ... and so was its search-prefix entry (ck)
+constexpr uint32_t A_CUR_KH = 1u << 22;   // ... which came from hash_tab: a located prefix of hash_order bases
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
 
 // prefetch pipeline of a lane: its next read (1) and the one after (2)
 constexpr uint32_t PF_W1 = 1u, PF_K1 = 2u, PF_W2 = 4u;        // record of 1, prefix entry of 1, record of 2 are here
 constexpr uint32_t PF_RW1 = 8u, PF_RK1 = 16u, PF_RW2 = 32u;   // ... are in flight this iteration
+constexpr uint32_t PF_H1 = 64u, PF_KH = 128u, PF_RH1 = 256u;  // hash_tab was asked about 1; it answered; in flight
 
 template <bool kLds>
 __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
@@ -158,6 +160,8 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   const uint64_t range_begin = wave * chunk;
   const uint64_t range_end = range_begin + chunk < a.n_reads ? range_begin + chunk : a.n_reads;
   const uint32_t K = ix.kmer_order;
+  const uint32_t H = ix.hash_order;  // 0: no hash table
+  const uint64_t hmask = (1ull << (2 * H)) - 1ull;
   const uint64_t kmask = (1ull << (2 * K)) - 1ull;  // K <= kMaxKmerOrder: the prefix lies in the first 32 bases, w_lo
   const uint32_t max_len = a.wpr * 16u;
 
@@ -181,15 +185,15 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   uint64_t nw_lo = 0, nw_hi = 0, nk = 0, mw_lo = 0, mw_hi = 0;  // records of rn (with its prefix entry) and rn2
 
   // interval after the search prefix, from a kmer_tab entry (device_layout.h)
-  auto apply_prefix = [&](uint64_t e) {
+  auto apply_prefix = [&](uint64_t e, uint32_t Kp) {  // Kp = bases the entry covers (kmer_order, or hash_order)
     uint64_t width = e >> kPosBits;
     if (e & kKmerLocated) {
       // one row, already located: straight to the text comparison when it can carry the rest of the read
       const uint64_t pos = e & kPosMask, run = (e >> kPosBits) & kKmerRunMax;
-      const uint64_t rem = (uint64_t)L - K;
+      const uint64_t rem = (uint64_t)L - Kp;
       if (rem >= 1 && run > rem && pos >= rem) {
         p = pos;
-        j = K;
+        j = Kp;
         lo = 0;  // the row itself is not needed: a comparison that dies reads it from pos_lines
         hi = 1;
         aux |= A_TRIED | A_DIRECT;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = hi = 0;
           st = S_FIN;
         } else if (had & A_CUR_K) {
-          apply_prefix(ck);
+          apply_prefix(ck, (had & A_CUR_KH) ? ix.hash_order : K);
           if (choose()) st = S_FIN;
         } else {
           st = S_KMER;
@@ -287,13 +291,14 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     // loads are unconditional so that all eight are in flight before the single wait)
     const uint4* const idle16 = reinterpret_cast<const uint4*>(a.packed);
     const uint64_t* const idle8 = reinterpret_cast<const uint64_t*>(a.packed);
-    const uint4* pa = idle16;    // 16 B
+    const uint4_a8* pa = reinterpret_cast<const uint4_a8*>(idle16);  // 16 B (8-byte aligned inside a PosLine)
     const uint4* pb = idle16;    // 16 B
     const uint4* pr = idle16;    // 16 B (read piece)
     const u64_a4* pc = idle8;    // 8 B (4-byte aligned when it points into a PosLine)
     const uint64_t* pe = idle8;  // 8 B
     const uint64_t* pk = idle8;  // 8 B (prefetch: prefix entry)
     const uint64_t* pl = idle8;  // 8 B (prefetch: the aligned 8 bytes holding a length)
+    const uint4* ph = idle16;    // 2 x 16 B (prefetch: one hash_tab bucket)
     const uint32_t* pd = a.packed;  // 4 B
     bool pair = false;           // S_KMER through the c_functions pair
     bool free_r = true;
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       case S_STEP_LO:
       case S_STEP_HI: {
         const Block2* b = ix.blocks2 + ((st == S_STEP_LO ? lo : hi) >> 6);
-        pa = reinterpret_cast<const uint4*>(&b->plane[0]);
+        pa = reinterpret_cast<const uint4_a8*>(&b->plane[0]);
         pb = reinterpret_cast<const uint4*>(&b->plane[2]);
         pd = &b->cnt[aux & 15u];
         tally += 1;
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       case S_LF1: {
         const Block1* bl = ix.blocks1 + (lo >> 6);
         const Block1* bh = ix.blocks1 + (hi >> 6);
-        pa = reinterpret_cast<const uint4*>(&bl->plane_lo);
+        pa = reinterpret_cast<const uint4_a8*>(&bl->plane_lo);
         pc = &bl->cnt[aux & 3u];
         pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
         pe = &bh->cnt[aux & 3u];
@@ -356,10 +361,17 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           sh = ob & 3u;
           tally += 1;
           if (slot + rem <= 128u) {  // the line holds the text too
+            // one 16-byte load from the 32-base word the window starts in when it ends inside those 64 bases
+            // (always for up to 33 remaining bases), else two from the 64-base word
             const uint32_t off = 128u - (slot + rem);
-            pa = reinterpret_cast<const uint4*>(lb) + (off >> 6);
-            pb = pa + 1;
-            o = off & 63u;
+            if ((off & 31u) + rem <= 64u) {
+              pa = reinterpret_cast<const uint4_a8*>(lb + 8u * (off >> 5));
+              o = off & 31u;
+            } else {
+              pa = reinterpret_cast<const uint4_a8*>(lb + 16u * (off >> 6));
+              pb = reinterpret_cast<const uint4*>(lb) + (off >> 6) + 1;
+              o = off & 63u;
+            }
             from_text = false;
           }
         } else {
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         }
         if (from_text) {
           const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
-          pa = t4;
+          pa = reinterpret_cast<const uint4_a8*>(t4);
           pb = t4 + 1;
           const uint64_t x1 = x0 + ((piece_end < L ? piece_end : L) - j) - 1;  // last base compared
           tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;                     // 512 bases per 128-byte line
@@ -402,18 +414,29 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           pf |= !(pf & PF_W1) ? PF_RW1 : PF_RW2;
         }
       }
-      if ((pf & (PF_W1 | PF_K1)) == PF_W1 && ix.kmer_tab && nL >= K && nL <= max_len) {
-        pk = ix.kmer_tab + ((~nw_lo) & kmask);
-        pf |= PF_RK1;
-        tally += 1;
+      if ((pf & (PF_W1 | PF_K1)) == PF_W1 && nL <= max_len) {
+        if (H && !(pf & PF_H1) && nL > H) {
+          // the hash table first: a located prefix of H bases, or nothing
+          const uint64_t vv = hash_mix((~nw_lo) & hmask, H);
+          ph = reinterpret_cast<const uint4*>(ix.hash_tab) + __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) * 2u;
+          pf |= PF_RH1;
+          tally += 1;
+        } else if (ix.kmer_tab && nL >= K) {
+          pk = ix.kmer_tab + ((~nw_lo) & kmask);
+          pf |= PF_RK1;
+          tally += 1;
+        }
       }
     }
     // The wave barriers are no instructions; being convergent they keep the compiler from duplicating the loads
     // into the per-state branches on either side, which would put a memory wait inside every branch.
     __builtin_amdgcn_wave_barrier();
-    const uint4 va = *pa, vb = *pb, vr = *pr;
+    const uint4_a8 va = *pa;
+    const uint4 vb = *pb, vr = *pr;
     const uint64_t vc = *pc, ve = *pe, vk = *pk, vl = *pl;
     const uint32_t vd = *pd;
+    uint4 vh0 = make_uint4(0, 0, 0, 0), vh1 = vh0;
+    if (H) { vh0 = ph[0]; vh1 = ph[1]; }  // wave-uniform condition
     __builtin_amdgcn_wave_barrier();
 
     if (pf & PF_RW1) {
@@ -430,6 +453,24 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     if (pf & PF_RK1) {
       nk = vk;
       pf = (pf | PF_K1) & ~PF_RK1;
+    }
+    if (pf & PF_RH1) {
+      // four slots: position << 24 | run << tag_bits | tag; an empty slot is all ones (no position is)
+      const uint64_t vv = hash_mix((~nw_lo) & hmask, H);
+      // (tag in the low word; the high word of an empty slot is all ones, that of a position never is)
+      const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u, tag = (uint32_t)vv & tmask;
+      const uint32_t sl_lo[4] = {vh0.x, vh0.z, vh1.x, vh1.z};
+      const uint32_t sl_hi[4] = {vh0.y, vh0.w, vh1.y, vh1.w};
+      uint64_t found = ~0ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) found = u64_of(sl_lo[q], sl_hi[q]);
+      pf = (pf | PF_H1) & ~PF_RH1;
+      if (found != ~0ull) {
+        const uint64_t run = (found & 0xFFFFFFull) >> ix.hash_tag_bits;
+        nk = kKmerLocated | (found >> 24) | (run << kPosBits);
+        pf |= PF_K1 | PF_KH;
+      }
     }
 
     // ---- consume
@@ -454,7 +495,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = vc;
           hi = ve;
         } else {
-          apply_prefix(vc);
+          apply_prefix(vc, K);
         }
         finish = choose();
         break;
@@ -646,7 +687,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       r = rn;
       rn = rn2;
       rn2 = ~0ull;
-      aux = ((pf & PF_W1) ? A_CUR_W : 0u) | ((pf & PF_K1) ? A_CUR_K : 0u);
+      aux = ((pf & PF_W1) ? A_CUR_W : 0u) | ((pf & PF_K1) ? A_CUR_K : 0u) | ((pf & PF_KH) ? A_CUR_KH : 0u);
       w_lo = nw_lo;
       w_hi = nw_hi;
       L = nL;

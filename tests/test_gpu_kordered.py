@@ -83,10 +83,12 @@ def test_tie_shuffled_index_matches_oracle(golden_dir, oracle, k, seed):
     npos_key = np.array([0, 3600, 3720, 6820], dtype=np.uint64)       # golden.json g2 ref_npos_map
     npos_val = np.array([0, 10, 5, 5], dtype=np.uint64)
     os.environ["SBWT_KMER_ORDER"] = ("12", "14", "13", "15")[seed]
+    os.environ["SBWT_HASH_ORDER"] = ("0", "20", "16", "0")[seed]
     ix = sb.Index.from_tables(0, T["interval"], T["n"], T["first_location"], len(fwd), T["c4"], T["cfs"],
                               [T["occ"][c] for c in range(4)], T["jbwt"], T["fbwt"], T["loc"], chr_start, npos_key,
                               npos_val, chr_names=["chr1", "chr2"])
     os.environ.pop("SBWT_KMER_ORDER")
+    os.environ.pop("SBWT_HASH_ORDER")
     L = oracle.lib()
     occs = [np.ascontiguousarray(T["occ"][c]) for c in range(4)]
     h = L.sbo_index_wrap(T["interval"], T["n"], T["first_location"], len(fwd), T["c4"].ctypes.data,

@@ -43,16 +43,19 @@ def sb():
     return sbwt_amd
 
 
-@pytest.fixture(scope="module", params=["12", "13", "14", "15", "16"])
+@pytest.fixture(scope="module", params=["12:0", "13:0", "14:0", "15:0", "16:0", "12:14", "14:19", "16:20", "13:28"])
 def loaded(request, sb, oracle, golden_indexes):
     """every test runs with no memoised search prefix (12) and with the 13- to 16-base tables the loader picks for
     larger indexes (forced here: the golden genomes are tiny); odd orders take one single-base step after the
     prefix; order 17, what a GRCh38-sized index gets, has a test of its own below (its table is 137 GB)"""
-    os.environ["SBWT_KMER_ORDER"] = request.param
+    # "direct order:hash order" -- the second is the hash table of located prefixes (0 = none) that larger indexes
+    # get on top of the direct table
+    os.environ["SBWT_KMER_ORDER"], os.environ["SBWT_HASH_ORDER"] = request.param.split(":")
     out = {}
     for g, prefix in golden_indexes.items():
         out[g] = (sb.Index.load(prefix), oracle.OracleIndex.load(prefix))
     os.environ.pop("SBWT_KMER_ORDER")
+    os.environ.pop("SBWT_HASH_ORDER")
     yield out
     for ix, oix in out.values():
         ix.close()
@@ -63,10 +66,12 @@ def test_order_17_prefix_table(sb, oracle, golden_indexes, golden_dir):
     """the 4^17-entry table (34-bit entry numbers) on the repeat genome: golden reads, every length 12..60 on
     both strands, substitutions"""
     os.environ["SBWT_KMER_ORDER"] = "17"
+    os.environ["SBWT_HASH_ORDER"] = "0"
     try:
         ix = sb.Index.load(golden_indexes["g2"])
     finally:
         os.environ.pop("SBWT_KMER_ORDER")
+        os.environ.pop("SBWT_HASH_ORDER")
     oix = oracle.OracleIndex.load(golden_indexes["g2"])
     chroms = []
     for line in open(os.path.join(golden_dir, "g2.fa")):

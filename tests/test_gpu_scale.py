@@ -48,8 +48,12 @@ def world(oracle):
     d_fwd = C.c_void_p()
     assert hip.hipMalloc(C.byref(d_fwd), host.nbytes) == 0
     assert hip.hipMemcpy(d_fwd, host.ctypes.data, host.nbytes, 1) == 0
-    ix, tables = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, interval=64, device=0,
-                                       want_index=True, want_tables=True)
+    os.environ["SBWT_HASH_ORDER"] = "20"     # what an index of 2^24 suffixes or more gets by itself
+    try:
+        ix, tables = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, interval=64, device=0,
+                                           want_index=True, want_tables=True)
+    finally:
+        os.environ.pop("SBWT_HASH_ORDER")
     hip.hipFree(d_fwd)
     T = tables.contents
     L_ = oracle.lib()
