@@ -334,8 +334,10 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         const Block1* bh = ix.blocks1 + (hi >> 6);
         pa = reinterpret_cast<const uint4_a8*>(&bl->plane_lo);
         pc = &bl->cnt[aux & 3u];
-        pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
-        pe = &bh->cnt[aux & 3u];
+        if (bl != bh) {  // both ends in one block: what was loaded for lo serves hi (a load request less each)
+          pb = reinterpret_cast<const uint4*>(&bh->plane_lo);
+          pe = &bh->cnt[aux & 3u];
+        }
         tally += bl == bh ? 1u : 2u;
         break;
       }
@@ -542,7 +544,9 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         const uint32_t c = aux & 3u;
         const uint32_t mode = (aux >> 8) & 3u;
         uint64_t l1 = vc + (uint64_t)__popcll(match1(u64_of(va.x, va.y), u64_of(va.z, va.w), c) & below((uint32_t)(lo & 63)));
-        uint64_t h1 = ve + (uint64_t)__popcll(match1(u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), c) & below((uint32_t)(hi & 63)));
+        const bool one_block = (lo >> 6) == (hi >> 6);
+        const uint64_t hp_lo = one_block ? u64_of(va.x, va.y) : u64_of(vb.x, vb.y), hp_hi = one_block ? u64_of(va.z, va.w) : u64_of(vb.z, vb.w);
+        uint64_t h1 = (one_block ? vc : ve) + (uint64_t)__popcll(match1(hp_lo, hp_hi, c) & below((uint32_t)(hi & 63)));
         if (c == 0 && lo > ix.first_location) l1 -= 1;
         if (c == 0 && hi > ix.first_location) h1 -= 1;
         if (mode == M_REPLAY) {
