@@ -347,45 +347,52 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         tally += 1;
         break;
       case S_CMP: {
-        // read[j + t] continues the match iff it equals textrc[x0 + t]; the last chunk also brings the final row
+        // read[j + t] continues the match iff it equals textrc[x0 + t].  The PosLine of the position the read
+        // ends on holds the 128 bases in front of it: when the rest of the read lies inside them, every 64-base
+        // piece is compared against that line, and the last piece finds the final row in it too.  One 16-byte
+        // load from the 32-base word the piece starts in when it ends inside those 64 bases, else two.
         const uint64_t x0 = ix.n - 1 - p;
         const uint32_t piece_end = (j | 63u) + 1u;
-        uint32_t o = (uint32_t)(x0 & 63), sh = 0;
-        bool from_text = true;
-        if (piece_end >= L) {
-          const uint32_t rem = L - j;
-          const uint64_t pfin = p - (uint64_t)rem;
-          const uint64_t line = pfin / kPosPerLine;
-          const uint32_t slot = (uint32_t)(pfin - line * kPosPerLine);
-          const char* lb = reinterpret_cast<const char*>(ix.pos_lines + line);
+        const bool last = piece_end >= L;
+        const uint32_t nb = (last ? L : piece_end) - j;  // bases compared now
+        const uint32_t rem = L - j;                      // bases to the end of the read
+        const uint64_t pfin = p - (uint64_t)rem;
+        const uint64_t line = pfin / kPosPerLine;
+        const uint32_t slot = (uint32_t)(pfin - line * kPosPerLine);
+        const char* lb = reinterpret_cast<const char*>(ix.pos_lines + line);
+        uint32_t o, sh = 0;
+        if (last) {
           const uint32_t ob = 32u + 5u * slot;
           pc = reinterpret_cast<const u64_a4*>(lb + (ob & ~3u));
           sh = ob & 3u;
           tally += 1;
-          if (slot + rem <= 128u) {  // the line holds the text too
-            // one 16-byte load from the 32-base word the window starts in when it ends inside those 64 bases
-            // (always for up to 33 remaining bases), else two from the 64-base word
-            const uint32_t off = 128u - (slot + rem);
-            if ((off & 31u) + rem <= 64u) {
-              pa = reinterpret_cast<const uint4_a8*>(lb + 8u * (off >> 5));
-              o = off & 31u;
-            } else {
-              pa = reinterpret_cast<const uint4_a8*>(lb + 16u * (off >> 6));
-              pb = reinterpret_cast<const uint4*>(lb) + (off >> 6) + 1;
-              o = off & 63u;
-            }
-            from_text = false;
-          }
         } else {
           pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
           free_r = false;
         }
-        if (from_text) {
-          const uint4* t4 = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
-          pa = reinterpret_cast<const uint4_a8*>(t4);
-          pb = t4 + 1;
-          const uint64_t x1 = x0 + ((piece_end < L ? piece_end : L) - j) - 1;  // last base compared
-          tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;                     // 512 bases per 128-byte line
+        if (slot + rem <= 128u) {
+          const uint32_t off = 128u - (slot + rem);
+          if ((off & 31u) + nb <= 64u) {
+            pa = reinterpret_cast<const uint4_a8*>(lb + 8u * (off >> 5));
+            o = off & 31u;
+          } else {
+            pa = reinterpret_cast<const uint4_a8*>(lb + 16u * (off >> 6));
+            pb = reinterpret_cast<const uint4*>(lb) + (off >> 6) + 1;
+            o = off & 63u;
+          }
+          if (!last) tally += 1;
+        } else {
+          const char* tb = reinterpret_cast<const char*>(ix.textrc);
+          if ((uint32_t)(x0 & 31) + nb <= 64u) {
+            pa = reinterpret_cast<const uint4_a8*>(tb + 8u * (x0 >> 5));
+            o = (uint32_t)(x0 & 31);
+          } else {
+            pa = reinterpret_cast<const uint4_a8*>(tb + 16u * (x0 >> 6));
+            pb = reinterpret_cast<const uint4*>(tb) + (x0 >> 6) + 1;
+            o = (uint32_t)(x0 & 63);
+          }
+          const uint64_t x1 = x0 + nb - 1;                      // last base compared
+          tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;      // 512 bases per 128-byte line
         }
         aux = (aux & ~0xffu) | o | (sh << 6);
         break;
