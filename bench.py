@@ -332,7 +332,7 @@ def main():
         oix = oracle_lib.OracleIndex(h)
         cores = min(16, os.cpu_count() or 1)
         probe_n = 20000
-        sample_max = 2_000_000
+        sample_max = 8_000_000
         host_packed = packed[:sample_max].cpu().numpy().view(np.uint32)
         host_lens = lens[:sample_max].cpu().numpy().astype(np.uint32)
         pseq, poff = unpack_reads(host_packed[:probe_n], host_lens[:probe_n])
