@@ -188,11 +188,11 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
   // full order of two rows given their offsets: prepended string (zero padded), its length, the offset
   auto row_less = [&](uint32_t ia, uint32_t ib) -> bool {
-    const uint64_t a0 = k0[ia], b0 = k0[ib];
-    if (a0 != b0) return a0 < b0;
-    const uint64_t a1 = k1[ia], b1 = k1[ib];
-    if (a1 != b1) return a1 < b1;
+    // all six words first: one LDS round trip instead of three
+    const uint64_t a0 = k0[ia], b0 = k0[ib], a1 = k1[ia], b1 = k1[ib];
     const uint32_t ta = (uint32_t)(pay[ia] >> 58), tb = (uint32_t)(pay[ib] >> 58);
+    if (a0 != b0) return a0 < b0;
+    if (a1 != b1) return a1 < b1;
     if (ta != tb) return ta < tb;
     return ia < ib;
   };
@@ -295,6 +295,28 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
           }
           team_sync<T>();
           continue;
+        }
+        // Rows whose left contexts agree over their whole length (copies of a repeat at the same phase of the
+        // sampling, say) are in emission order as they stand, and every comparison among them would take the
+        // full-key path: one pass finds out whether the words are in order already.
+        {
+          bool in_order = true;
+          for (uint32_t i = tid; i + 1 < N; i += T) {
+            const uint64_t ka = key[i], kb = key[i + 1];
+            bool less = ka < kb;
+            if (((ka ^ kb) >> 16) == 0) less = row_less((uint32_t)ka & 0xFFFFu, (uint32_t)kb & 0xFFFFu);
+            in_order = in_order && less;
+          }
+          const bool wave_ok = __all(in_order);
+          if (T == 256) {
+            if (lane == 0) s_scan_all[threadIdx.x >> 6] = wave_ok ? 1u : 0u;
+            __syncthreads();
+            in_order = (s_scan_all[0] & s_scan_all[1] & s_scan_all[2] & s_scan_all[3]) != 0;
+            __syncthreads();
+          } else {
+            in_order = wave_ok;
+          }
+          if (in_order) N = 0;  // nothing to sort
         }
         // bitonic sort of the N words in LDS; the full keys are looked up only for words whose first 24 bases agree
         for (uint32_t size = 2; size <= N; size <<= 1) {
