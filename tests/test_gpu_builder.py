@@ -83,3 +83,33 @@ def test_cli_build_then_map(sb, golden_dir, tmp_path):
     assert open(sam, "rb").read() == open(os.path.join(golden_dir, "g1.sam"), "rb").read()
     r = subprocess.run([exe, "map", "-i", os.path.join(golden_dir, "g1.fq"), "-p", prefix], capture_output=True)
     assert r.stdout == open(os.path.join(golden_dir, "g1.sam"), "rb").read()  # stdout by default
+
+
+def test_g3_config1_index_and_sam_md5_equal_the_reference_binary(sb, golden_dir, tmp_path):
+    """BASELINE.json configs[0] stand-in: 4,641,652-bp genome, 1 M 50-bp reads.  The GPU builder's
+    t_table.bwt and the GPU mapper's SAM must have the md5 sums recorded from the upstream binary's own files."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    gold = json.load(open(os.path.join(golden_dir, "golden.json")))["g3"]
+    subprocess.check_call([sys.executable, os.path.join(golden_dir, "make_inputs.py"), str(tmp_path), "g3"])
+
+    def md5(path):
+        h = hashlib.md5()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 22), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    assert md5(str(tmp_path / "g3.fa")) == gold["input_fa_md5"]
+    prefix = str(tmp_path / "g3")
+    sb.build_index(str(tmp_path / "g3.fa"), prefix)
+    assert md5(prefix + ".t_table.bwt") == gold["ref_t_table_md5"]
+    ix = sb.Index.load(prefix)
+    for nt in (1, 8):
+        sam = str(tmp_path / ("o%d.sam" % nt))
+        st = ix.map_fastq(str(tmp_path / "g3.fq"), sam, n_threads=nt)
+        assert st[0] == 1_000_000
+        assert md5(sam) == gold["ref_sam_md5"]
+    ix.close()
