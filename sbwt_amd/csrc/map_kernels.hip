@@ -200,8 +200,8 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
       c->sm_lds_bytes = (((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super + 1) & ~(size_t)1) * sizeof(uint64_t);
     int sm_lds = 0, sm_glb = 0;
     if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true>, 256, c->sm_lds_bytes + ring_bytes);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false>, 256, ring_bytes);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true, true>, 256, c->sm_lds_bytes + ring_bytes);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false, true>, 256, ring_bytes);
     int sort_per_cu = 0;
     if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys) c->sort_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, c->sort_lds_bytes);
@@ -312,8 +312,12 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     const bool lds = c->sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);
-    if (lds) k_search_sm<true><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
-    else k_search_sm<false><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
+    // records of 65..128 bases: the variant that compares 128 bases at once (longer records gain nothing from it)
+    const bool long_reads = words_per_read == 8;
+    if (lds && long_reads) k_search_sm<true, true><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
+    else if (lds) k_search_sm<true, false><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
+    else if (long_reads) k_search_sm<false, true><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
+    else k_search_sm<false, false><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
     SBWT_LAUNCHED();
     n_waves = grid * 4;
     chunk = ((n_reads + n_waves - 1) / n_waves + 63) & ~63ull;  // as k_search_sm splits the batch

@@ -125,14 +125,19 @@ constexpr uint32_t A_PIECE = 1u << 19;    // w holds the read piece j is in (set
 constexpr uint32_t A_CUR_W = 1u << 20;    // S_START: the read's record was prefetched (w_lo, w_hi, L)
 constexpr uint32_t A_CUR_K = 1u << 21;    // ... and so was its search-prefix entry (ck)
 constexpr uint32_t A_CUR_KH = 1u << 22;   // ... which came from hash_tab: a located prefix of hash_order bases
+constexpr uint32_t A_CUR_P2 = 1u << 23;   // (long-read variant) w2 holds bases 64..127 of the read, for its whole life
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
 
 // prefetch pipeline of a lane: its next read (1) and the one after (2)
 constexpr uint32_t PF_W1 = 1u, PF_K1 = 2u, PF_W2 = 4u;        // record of 1, prefix entry of 1, record of 2 are here
 constexpr uint32_t PF_RW1 = 8u, PF_RK1 = 16u, PF_RW2 = 32u;   // ... are in flight this iteration
 constexpr uint32_t PF_H1 = 64u, PF_KH = 128u, PF_RH1 = 256u;  // hash_tab was asked about 1; it answered; in flight
+constexpr uint32_t PF_P1 = 1024u, PF_RP1 = 2048u;             // (long-read variant) second 64-base piece of 1: here; in flight
 
-template <bool kLds>
+// kLong: the variant launched for batches whose records hold more than 64 bases.  A lane also prefetches the second
+// 64-base piece of its next read, and a text comparison that ends within the first 128 bases of the read runs in
+// ONE iteration against the whole 128-base window of the PosLine (instead of one iteration and one access per piece).
+template <bool kLds, bool kLong>
 __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_mem[];
   SmTables T{ix.chr_start, ix.npos_key, ix.npos_val, ix.sb_abs};
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0;
   uint64_t ck = 0;                                     // prefix entry of the read about to start
   uint64_t nw_lo = 0, nw_hi = 0, nk = 0, mw_lo = 0, mw_hi = 0;  // records of rn (with its prefix entry) and rn2
+  uint64_t w2_lo = 0, w2_hi = 0, nw2_lo = 0, nw2_hi = 0;        // kLong: bases 64..127 of the current read and of rn
 
   // interval after the search prefix, from a kmer_tab entry (device_layout.h)
   auto apply_prefix = [&](uint64_t e, uint32_t Kp) {  // Kp = bases the entry covers (kmer_order, or hash_order)
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     if (st == S_START && r < flushed + kSmRing) {
       reserve = true;
       const uint32_t had = aux;
-      aux = 0;
+      aux = had & A_CUR_P2;
       flags = 0;
       if (!(had & A_CUR_W)) {
         st = S_FETCH;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint64_t* pk = idle8;  // 8 B (prefetch: prefix entry)
     const uint64_t* pl = idle8;  // 8 B (prefetch: the aligned 8 bytes holding a length)
     const uint4* ph = idle16;    // 2 x 16 B (prefetch: one hash_tab bucket)
+    const uint4* pr2 = idle16;   // 16 B (kLong; prefetch: second piece of the next read)
     const uint32_t* pd = a.packed;  // 4 B
     bool pair = false;           // S_KMER through the c_functions pair
     bool free_r = true;
@@ -361,6 +368,17 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         const uint32_t slot = (uint32_t)(pfin - line * kPosPerLine);
         const char* lb = reinterpret_cast<const char*>(ix.pos_lines + line);
         uint32_t o, sh = 0;
+        const bool full = kLong && (aux & A_CUR_P2) && !last && L <= 128u && j < 64u && slot + rem <= 128u;
+        if (full) {
+          // the rest of the read against the whole window, and the final row: one access
+          const uint32_t ob = 32u + 5u * slot;
+          pc = reinterpret_cast<const u64_a4*>(lb + (ob & ~3u));
+          pa = reinterpret_cast<const uint4_a8*>(lb);
+          pb = reinterpret_cast<const uint4*>(lb) + 1;
+          tally += 1;
+          aux = (aux & ~0x3ffu) | (128u - (slot + rem)) | ((ob & 3u) << 7) | 0x200u;
+          break;
+        }
         if (last) {
           const uint32_t ob = 32u + 5u * slot;
           pc = reinterpret_cast<const u64_a4*>(lb + (ob & ~3u));
@@ -394,14 +412,14 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           const uint64_t x1 = x0 + nb - 1;                      // last base compared
           tally += (uint32_t)((x1 >> 9) - (x0 >> 9)) + 1u;      // 512 bases per 128-byte line
         }
-        aux = (aux & ~0xffu) | o | (sh << 6);
+        aux = (aux & ~0x3ffu) | o | (sh << 7);
         break;
       }
       case S_MISROW: {
         const uint64_t line = p / kPosPerLine;
         const uint32_t ob = 32u + 5u * (uint32_t)(p - line * kPosPerLine);
         pc = reinterpret_cast<const u64_a4*>(reinterpret_cast<const char*>(ix.pos_lines + line) + (ob & ~3u));
-        aux = (aux & ~0xffu) | ((ob & 3u) << 6);
+        aux = (aux & ~0x3ffu) | ((ob & 3u) << 7);
         tally += 1;
         break;
       }
@@ -422,6 +440,10 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           pl = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(a.lens + q) & ~(uintptr_t)7);
           pf |= !(pf & PF_W1) ? PF_RW1 : PF_RW2;
         }
+      }
+      if (kLong && (pf & (PF_W1 | PF_P1)) == PF_W1 && nL > 64u && nL <= max_len) {
+        pr2 = reinterpret_cast<const uint4*>(a.packed + rn * (uint64_t)a.wpr) + 1;
+        pf |= PF_RP1;
       }
       if ((pf & (PF_W1 | PF_K1)) == PF_W1 && nL <= max_len) {
         if (H && !(pf & PF_H1) && nL > H) {
@@ -446,6 +468,8 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint32_t vd = *pd;
     uint4 vh0 = make_uint4(0, 0, 0, 0), vh1 = vh0;
     if (H) { vh0 = ph[0]; vh1 = ph[1]; }  // wave-uniform condition
+    uint4 vr2 = make_uint4(0, 0, 0, 0);
+    if (kLong) vr2 = *pr2;
     __builtin_amdgcn_wave_barrier();
 
     if (pf & PF_RW1) {
@@ -462,6 +486,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     if (pf & PF_RK1) {
       nk = vk;
       pf = (pf | PF_K1) & ~PF_RK1;
+    }
+    if (kLong && (pf & PF_RP1)) {
+      nw2_lo = u64_of(vr2.x, vr2.y);
+      nw2_hi = u64_of(vr2.z, vr2.w);
+      pf = (pf | PF_P1) & ~PF_RP1;
     }
     if (pf & PF_RH1) {
       // four slots: position << 24 | run << tag_bits | tag; an empty slot is all ones (no position is)
@@ -582,9 +611,45 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         break;
       }
       case S_CMP: {
+        if (kLong && (aux & 0x200u)) {
+          // bases [j, L), L <= 128, against the 128-base window of the PosLine from offset o on
+          const uint32_t o = aux & 127u, nb = L - j;
+          const uint64_t q0 = u64_of(va.x, va.y), q1 = u64_of(va.z, va.w), q2 = u64_of(vb.x, vb.y), q3 = u64_of(vb.z, vb.w);
+          uint64_t t0, t1, t2 = 0, t3 = 0, r0, r1, r2, r3;
+          if (o < 64u) {
+            sm_funnel128(q0, q1, q2, q3, o, t0, t1);
+            sm_funnel128(q2, q3, 0, 0, o, t2, t3);
+          } else {
+            sm_funnel128(q2, q3, 0, 0, o - 64u, t0, t1);
+          }
+          sm_funnel128(w_lo, w_hi, w2_lo, w2_hi, j, r0, r1);  // j < 64
+          sm_funnel128(w2_lo, w2_hi, 0, 0, j, r2, r3);
+          uint64_t d[4] = {r0 ^ t0, r1 ^ t1, r2 ^ t2, r3 ^ t3};
+          uint32_t t = nb;
+#pragma unroll
+          for (int q = 3; q >= 0; --q) {
+            const uint32_t first = 32u * (uint32_t)q;  // this word covers bases [first, first + 32) of the nb
+            uint64_t dq = d[q];
+            if (nb <= first) dq = 0;
+            else if (nb < first + 32u) dq &= (1ull << (2 * (nb - first))) - 1ull;
+            if (dq) t = first + ((uint32_t)(__ffsll((unsigned long long)dq) - 1) >> 1);
+          }
+          j += t;
+          p -= t;
+          if (j >= 64u) { w_lo = w2_lo; w_hi = w2_hi; }  // w holds the piece j is in
+          if (t < nb) {
+            st = S_MISROW;
+          } else {
+            lo = (vc >> (8u * ((aux >> 7) & 3u))) & kPosMask;
+            hi = lo + 1;
+            aux |= A_LOCATED;
+            finish = true;
+          }
+          break;
+        }
         // bases [j, min(L, end of the read's 64-base piece)) against the text at x0.. (device_index.hip: text-jump)
         uint64_t t0, t1, r0, r1;
-        sm_funnel128(u64_of(va.x, va.y), u64_of(va.z, va.w), u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), aux & 63u, t0, t1);
+        sm_funnel128(u64_of(va.x, va.y), u64_of(va.z, va.w), u64_of(vb.x, vb.y), u64_of(vb.z, vb.w), aux & 127u, t0, t1);
         sm_funnel128(w_lo, w_hi, 0, 0, j & 63u, r0, r1);
         const uint32_t piece_end = (j | 63u) + 1u;
         const uint32_t stop = piece_end < L ? piece_end : L;
@@ -601,7 +666,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         if (t < nb) {
           st = S_MISROW;  // the chain dies at base j: exec_exact_match on the row of text position p
         } else if (j == L) {
-          lo = (vc >> (8u * ((aux >> 6) & 3u))) & kPosMask;  // the row the chain ends on (row of position p)
+          lo = (vc >> (8u * ((aux >> 7) & 3u))) & kPosMask;  // the row the chain ends on (row of position p)
           hi = lo + 1;
           aux |= A_LOCATED;  // the position is p
           finish = true;
@@ -612,7 +677,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         break;
       }
       case S_MISROW: {
-        lo = (vc >> (8u * ((aux >> 6) & 3u))) & kPosMask;
+        lo = (vc >> (8u * ((aux >> 7) & 3u))) & kPosMask;
         hi = lo + 1;
         const uint32_t c = ((uint32_t)((j & 32u ? w_hi : w_lo) >> (2 * (j & 31u))) & 3u) ^ 3u;
         aux = (aux & ~0x3ffu) | c | (M_DEAD << 8);
@@ -699,6 +764,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       rn = rn2;
       rn2 = ~0ull;
       aux = ((pf & PF_W1) ? A_CUR_W : 0u) | ((pf & PF_K1) ? A_CUR_K : 0u) | ((pf & PF_KH) ? A_CUR_KH : 0u);
+      if (kLong) {
+        if (pf & PF_P1) aux |= A_CUR_P2;
+        w2_lo = nw2_lo;
+        w2_hi = nw2_hi;
+      }
       w_lo = nw_lo;
       w_hi = nw_hi;
       L = nL;

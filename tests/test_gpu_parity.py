@@ -123,6 +123,34 @@ def test_suppression_limit(sb, loaded, golden_dir, limit):
 
 
 @pytest.mark.parametrize("g", ["g1", "g2"])
+def test_reads_of_65_to_128_bases(sb, loaded, golden_dir, g):
+    """batches whose records hold 65..128 bases run the kernel variant that compares up to 128 bases in one
+    step: every length 60..128 (a few shorter ones ride in the same records), both strands, substitutions at
+    every depth, three strand filters"""
+    ix, oix = loaded[g]
+    seq = genome_text(os.path.join(golden_dir, g + ".fa"))
+    rng = np.random.default_rng(128)
+    reads = []
+    for L in list(range(60, 129)) + [12, 20, 21, 33, 50]:
+        for _ in range(40):
+            p = int(rng.integers(0, len(seq) - L))
+            s = seq[p:p + L]
+            if "N" in s:
+                continue
+            if rng.random() < 0.5:
+                s = s.translate(COMP)[::-1]
+            if rng.random() < 0.4:
+                k = int(rng.integers(0, L))
+                s = s[:k] + "ACGT"[int(rng.integers(0, 4))] + s[k + 1:]
+            reads.append(s)
+    assert max(len(r) for r in reads) == 128 and sb.words_per_read(128) == 8
+    ctx = sb.Context(ix, len(reads))
+    for strand in (2, 0, 1):
+        res, _ = assert_same(sb, ctx, oix, reads, strand=strand)
+    ctx.close()
+
+
+@pytest.mark.parametrize("g", ["g1", "g2"])
 def test_random_reads_all_lengths(sb, loaded, golden_dir, g):
     """substrings of both strands, lengths 12..200 (odd and even step counts, 1..4 sixteen-byte chunks),
     30 % with one substitution so the interval dies at every possible step parity"""
