@@ -323,3 +323,49 @@ def test_hits_layout_and_capacity_retry(sb, loaded, golden_dir):
     assert len(multi) == 2 and (res["first_hit"][multi] >= n).all()
     assert ctx.last_stats()[2] == n + 6 and ctx.last_stats()[0] > 0
     ctx.close()
+
+
+def test_two_contexts_map_concurrently(sb, loaded, golden_dir):
+    """calls on distinct sbwt_ctx objects may run concurrently (include/sbwt_amd.h; the upstream pool's functor
+    calls do): two host threads, one ctx and stream each, same index, many batches"""
+    import threading
+    ix, oix = loaded["g2"]
+    seq = genome_text(os.path.join(golden_dir, "g2.fa"))
+    rng = np.random.default_rng(2)
+    batches = []
+    for b in range(2):
+        reads = []
+        for _ in range(3000):
+            L = int(rng.integers(12, 101))
+            p = int(rng.integers(0, len(seq) - L))
+            s = seq[p:p + L]
+            if "N" in s:
+                continue
+            if rng.random() < 0.5:
+                s = s.translate(COMP)[::-1]
+            reads.append(s)
+        batches.append(reads)
+    want = [oix.map_batch(reads) for reads in batches]
+    errors = []
+
+    def work(k):
+        try:
+            ctx = sb.Context(ix, len(batches[k]))
+            packed, lens = sb.pack_reads(batches[k])
+            for _ in range(20):
+                res, hits = ctx.map_batch(packed, lens)
+                lo, hi, nh, first, ohits = want[k]
+                assert np.array_equal(res["sa_lo"], lo) and np.array_equal(res["sa_hi"], hi) and np.array_equal(res["nh"], nh)
+                for r in np.nonzero(nh)[0][:200]:
+                    a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
+                    assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])])
+            ctx.close()
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
