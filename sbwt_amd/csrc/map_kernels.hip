@@ -312,8 +312,8 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     const bool lds = c->sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);
-    // records of 65..128 bases: the variant that compares 128 bases at once (longer records gain nothing from it)
-    const bool long_reads = words_per_read == 8;
+    // records of more than 64 bases: the variant that holds two 64-base pieces and compares up to 128 bases at once
+    const bool long_reads = words_per_read > 4;
     if (lds && long_reads) k_search_sm<true, true><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
     else if (lds) k_search_sm<true, false><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
     else if (long_reads) k_search_sm<false, true><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);

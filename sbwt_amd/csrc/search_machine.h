@@ -125,7 +125,8 @@ constexpr uint32_t A_PIECE = 1u << 19;    // w holds the read piece j is in (set
 constexpr uint32_t A_CUR_W = 1u << 20;    // S_START: the read's record was prefetched (w_lo, w_hi, L)
 constexpr uint32_t A_CUR_K = 1u << 21;    // ... and so was its search-prefix entry (ck)
 constexpr uint32_t A_CUR_KH = 1u << 22;   // ... which came from hash_tab: a located prefix of hash_order bases
-constexpr uint32_t A_CUR_P2 = 1u << 23;   // (long-read variant) w2 holds bases 64..127 of the read, for its whole life
+constexpr uint32_t A_CUR_P2 = 1u << 23;   // (long-read variant) w2 holds the 64-base piece after the one in w
+constexpr uint32_t A_REQ_P2 = 1u << 25;   // (long-read variant) ... and is on its way with the next piece
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
 
 // prefetch pipeline of a lane: its next read (1) and the one after (2)
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint4* pr2 = idle16;   // 16 B (kLong; prefetch: second piece of the next read)
     const uint32_t* pd = a.packed;  // 4 B
     bool pair = false;           // S_KMER through the c_functions pair
-    bool free_r = true;
+    bool free_r = true, free_r2 = true;
     switch (st) {
       case S_FETCH:
         pr = reinterpret_cast<const uint4*>(rp);
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         const uint32_t slot = (uint32_t)(pfin - line * kPosPerLine);
         const char* lb = reinterpret_cast<const char*>(ix.pos_lines + line);
         uint32_t o, sh = 0;
-        const bool full = kLong && (aux & A_CUR_P2) && !last && L <= 128u && j < 64u && slot + rem <= 128u;
+        const bool full = kLong && (aux & A_CUR_P2) && !last && (j & 63u) + rem <= 128u && slot + rem <= 128u;
         if (full) {
           // the rest of the read against the whole window, and the final row: one access
           const uint32_t ob = 32u + 5u * slot;
@@ -387,6 +388,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         } else {
           pr = reinterpret_cast<const uint4*>(rp) + (piece_end >> 6);  // next piece of the read
           free_r = false;
+          if (kLong && ((piece_end >> 6) + 2u) * 4u <= a.wpr) {  // ... and the one after it, when the record has one
+            pr2 = pr + 1;
+            free_r2 = false;
+            aux |= A_REQ_P2;
+          }
         }
         if (slot + rem <= 128u) {
           const uint32_t off = 128u - (slot + rem);
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           pf |= !(pf & PF_W1) ? PF_RW1 : PF_RW2;
         }
       }
-      if (kLong && (pf & (PF_W1 | PF_P1)) == PF_W1 && nL > 64u && nL <= max_len) {
+      if (kLong && free_r2 && (pf & (PF_W1 | PF_P1)) == PF_W1 && nL > 64u && nL <= max_len) {
         pr2 = reinterpret_cast<const uint4*>(a.packed + rn * (uint64_t)a.wpr) + 1;
         pf |= PF_RP1;
       }
@@ -622,8 +628,9 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           } else {
             sm_funnel128(q2, q3, 0, 0, o - 64u, t0, t1);
           }
-          sm_funnel128(w_lo, w_hi, w2_lo, w2_hi, j, r0, r1);  // j < 64
-          sm_funnel128(w2_lo, w2_hi, 0, 0, j, r2, r3);
+          const uint32_t jo = j & 63u;  // w holds the piece j is in, w2 the next
+          sm_funnel128(w_lo, w_hi, w2_lo, w2_hi, jo, r0, r1);
+          sm_funnel128(w2_lo, w2_hi, 0, 0, jo, r2, r3);
           uint64_t d[4] = {r0 ^ t0, r1 ^ t1, r2 ^ t2, r3 ^ t3};
           uint32_t t = nb;
 #pragma unroll
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           }
           j += t;
           p -= t;
-          if (j >= 64u) { w_lo = w2_lo; w_hi = w2_hi; }  // w holds the piece j is in
+          if (jo + t >= 64u) { w_lo = w2_lo; w_hi = w2_hi; aux &= ~A_CUR_P2; }  // w holds the piece j is in
           if (t < nb) {
             st = S_MISROW;
           } else {
@@ -673,7 +680,16 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         } else {
           w_lo = u64_of(vr.x, vr.y);  // next piece of the read
           w_hi = u64_of(vr.z, vr.w);
+          if (kLong) {
+            aux &= ~A_CUR_P2;
+            if (aux & A_REQ_P2) {
+              w2_lo = u64_of(vr2.x, vr2.y);
+              w2_hi = u64_of(vr2.z, vr2.w);
+              aux |= A_CUR_P2;
+            }
+          }
         }
+        if (kLong) aux &= ~A_REQ_P2;
         break;
       }
       case S_MISROW: {
@@ -687,6 +703,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       case S_REFETCH: {
         w_lo = u64_of(vr.x, vr.y);
         w_hi = u64_of(vr.z, vr.w);
+        aux &= ~A_CUR_P2;  // w2 is no longer the piece after w
         finish = choose();
         break;
       }
