@@ -150,6 +150,31 @@ def test_reads_of_65_to_128_bases(sb, loaded, golden_dir, g):
     ctx.close()
 
 
+def test_reads_of_129_to_260_bases(sb, loaded, golden_dir):
+    """three to five 64-base pieces: the long-read variant compares the first piece alone and then two pieces at a
+    time; substitutions at every depth kill the comparison in any piece"""
+    ix, oix = loaded["g1"]
+    seq = genome_text(os.path.join(golden_dir, "g1.fa"))
+    rng = np.random.default_rng(260)
+    reads = []
+    for L in list(range(129, 261, 2)) + [64, 100, 128]:
+        for _ in range(24):
+            p = int(rng.integers(0, len(seq) - L))
+            s = seq[p:p + L]
+            if "N" in s:
+                continue
+            if rng.random() < 0.5:
+                s = s.translate(COMP)[::-1]
+            if rng.random() < 0.5:
+                k = int(rng.integers(0, L))
+                s = s[:k] + "ACGT"[int(rng.integers(0, 4))] + s[k + 1:]
+            reads.append(s)
+    ctx = sb.Context(ix, len(reads))
+    res, _ = assert_same(sb, ctx, oix, reads)
+    assert (res["nh"] > 0).sum() > len(reads) // 3
+    ctx.close()
+
+
 @pytest.mark.parametrize("g", ["g1", "g2"])
 def test_random_reads_all_lengths(sb, loaded, golden_dir, g):
     """substrings of both strands, lengths 12..200 (odd and even step counts, 1..4 sixteen-byte chunks),
