@@ -772,10 +772,15 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     d.hash_order = 0;
     d.hash_buckets = 0;
     d.hash_tag_bits = 0;
+    // both prefix tables are optional: an allocation that fails (fragmented or shared device memory) leaves the
+    // index without that table, slower and with the same results
+    uint64_t* htab = nullptr;
+    if (H && dev_alloc(ix, &htab, n_buckets * kHashSlots)) {
+      (void)hipGetLastError();
+      H = 0;
+    }
     if (H) {
-      uint64_t* htab = nullptr;
       unsigned long long* d_counts = nullptr;
-      if (int rc = dev_alloc(ix, &htab, n_buckets * kHashSlots)) return rc;
       SBWT_HIP(hipMalloc(&d_counts, 16));
       SBWT_HIP(hipMemset(d_counts, 0, 16));
       SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (8 * kHashSlots)));
@@ -793,9 +798,13 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     }
     d.kmer_order = K;
     d.kmer_tab = nullptr;
+    uint64_t* tab = nullptr;
+    if (K > (uint32_t)kKmer && dev_alloc(ix, &tab, 1ull << (2 * K))) {
+      (void)hipGetLastError();
+      K = kKmer;
+      d.kmer_order = K;
+    }
     if (K > (uint32_t)kKmer) {
-      uint64_t* tab = nullptr;
-      if (int rc = dev_alloc(ix, &tab, 1ull << (2 * K))) return rc;
       k_kmer_table<<<grid_for(1ull << (2 * K), 256), 256>>>(d, K, tab);
       SBWT_LAUNCHED();
       d.kmer_tab = tab;
