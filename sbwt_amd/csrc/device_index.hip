@@ -734,9 +734,9 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     size_t free_b = 0, total_b = 0;
     SBWT_HIP(hipMemGetInfo(&free_b, &total_b));
     constexpr uint64_t kKmerHeadroom = 24ull << 30;
-    // hash table of located order-20 prefixes (device_layout.h): 1.6 slots per suffix, on indexes of 2^24 suffixes
+    // hash table of located order-20 prefixes (device_layout.h): 1.6 slots per suffix, on indexes of 2^22 suffixes
     // or more when it fits next to an order-16 direct table; SBWT_HASH_ORDER overrides (0 = none)
-    uint32_t H = raw.n >= (1ull << 24) ? 20u : 0u;
+    uint32_t H = raw.n >= (1ull << 22) ? 20u : 0u;
     if (const char* e = getenv("SBWT_HASH_ORDER")) {
       const int want = atoi(e);
       if (want == 0 || (want > kKmer && want <= (int)kHashMaxOrder)) H = (uint32_t)want;

@@ -48,7 +48,7 @@ def world(oracle):
     d_fwd = C.c_void_p()
     assert hip.hipMalloc(C.byref(d_fwd), host.nbytes) == 0
     assert hip.hipMemcpy(d_fwd, host.ctypes.data, host.nbytes, 1) == 0
-    os.environ["SBWT_HASH_ORDER"] = "20"     # what an index of 2^24 suffixes or more gets by itself
+    os.environ["SBWT_HASH_ORDER"] = "20"     # (an index of 2^22 suffixes or more gets it by itself; stated for clarity)
     try:
         ix, tables = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, interval=64, device=0,
                                            want_index=True, want_tables=True)
