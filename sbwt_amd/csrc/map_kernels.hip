@@ -161,6 +161,8 @@ struct sbwt_ctx {
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
   size_t sort_lds_bytes = 0;                  // filter tables of k_multi_sort in LDS (0: they stay in global memory)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
   uint64_t last_stats[4] = {0, 0, 0, 0};
   // staging for the host-buffer entry point
@@ -190,6 +192,10 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (c->multi_lanes > max_reads) c->multi_lanes = (uint32_t)((max_reads + 255) / 256 * 256);
   if (e == hipSuccess) e = hipMalloc(&c->d_stacks, (uint64_t)c->multi_lanes * ix->d.interval * sizeof(Frame));
   for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking);
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, ix->device);
@@ -234,6 +240,11 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits);
   for (int k = 0; k < 3; ++k)
     if (c->ev[k]) hipEventDestroy(c->ev[k]);
+  for (int k = 0; k < 2; ++k)
+    if (c->ev_in[k]) hipEventDestroy(c->ev_in[k]);
+  if (c->ev_k) hipEventDestroy(c->ev_k);
+  if (c->s_in) hipStreamDestroy(c->s_in);
+  if (c->s_out) hipStreamDestroy(c->s_out);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -254,6 +265,18 @@ extern "C" int sbwt_ctx_last_timing(const sbwt_ctx* c, float ms[3]) {
   for (int k = 0; k < 3; ++k) ms[k] = c->last_ms[k];
   return SBWT_OK;
 }
+
+// first_hit of every read with hits += bias (a sub-batch numbers its reads and its hit slots from 0)
+__global__ __launch_bounds__(256) void k_bias_first_hit(sbwt_read_result* __restrict__ results, uint64_t n, uint64_t bias) {
+  const uint64_t r = global_thread();
+  if (r < n && results[r].nh > 0) results[r].first_hit += bias;
+}
+
+// One device pass over n_reads reads.  Unique hits go to d_hits[read index], multi-hit lists to d_hits[multi_base ..)
+// (multi_base = n_reads for a whole batch); *multi_used = slots the lists took.  Synchronises the ctx stream.
+static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                    uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate);
 
 extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                                      uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results,
@@ -278,6 +301,18 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     return SBWT_ERR_CAPACITY;
   }
   SBWT_HIP(hipSetDevice(c->ix->device));
+  uint64_t multi_used = 0;
+  const int rc = map_pass(c, d_packed, d_lens, n_reads, words_per_read, limit, strand, d_results, d_hits, hits_cap, n_reads,
+                          &multi_used, false);
+  const uint64_t used = n_reads + multi_used;  // one slot per read + the multi-hit lists
+  c->last_stats[2] = used;
+  if (n_hits_host) *n_hits_host = used;        // on SBWT_ERR_CAPACITY: what a retry needs
+  return rc;
+}
+
+static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                    uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate) {
   MapArgs a;
   a.packed = d_packed;
   a.lens = d_lens;
@@ -325,7 +360,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
   {
     // multi-hit reads: gather + sort where the tables allow it, the upstream depth-first walk for the rest
-    k_multi_plan<<<1, 1024, 0, c->stream>>>(c->d_wave_info, n_waves, n_reads, hits_cap, &c->d_ctr->hit_count,
+    k_multi_plan<<<1, 1024, 0, c->stream>>>(c->d_wave_info, n_waves, multi_base, hits_cap, &c->d_ctr->hit_count,
                                             &c->d_ctr->multi_count, &c->d_ctr->overflow);
     SBWT_LAUNCHED();
     MultiSortArgs ms;
@@ -333,7 +368,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     ms.strand = strand;
     ms.results = d_results;
     ms.hits = d_hits;
-    ms.n_reads = n_reads;
+    ms.multi_base = multi_base;
     ms.queue = c->d_queue;
     ms.wave_info = c->d_wave_info;
     ms.n_waves = n_waves;
@@ -354,23 +389,22 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
   SBWT_HIP(hipStreamSynchronize(c->stream));
   SBWT_HIP(hipGetLastError());
-  hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[2]);
-  hipEventElapsedTime(&c->last_ms[1], c->ev[0], c->ev[1]);
-  hipEventElapsedTime(&c->last_ms[2], c->ev[1], c->ev[2]);
-  const uint64_t used = n_reads + c->h_ctr->hit_count;  // one slot per read + the multi-hit lists
-  c->last_stats[0] = c->h_ctr->index_accesses;
-  c->last_stats[1] = c->h_ctr->multi_count;
-  c->last_stats[3] = c->h_ctr->dfs_count;
-  c->last_stats[2] = used;
+  float ms[3] = {0, 0, 0};
+  hipEventElapsedTime(&ms[0], c->ev[0], c->ev[2]);
+  hipEventElapsedTime(&ms[1], c->ev[0], c->ev[1]);
+  hipEventElapsedTime(&ms[2], c->ev[1], c->ev[2]);
+  for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + ms[k] : ms[k];
+  c->last_stats[0] = (accumulate ? c->last_stats[0] : 0) + c->h_ctr->index_accesses;
+  c->last_stats[1] = (accumulate ? c->last_stats[1] : 0) + c->h_ctr->multi_count;
+  c->last_stats[3] = (accumulate ? c->last_stats[3] : 0) + c->h_ctr->dfs_count;
+  *multi_used = c->h_ctr->hit_count;
   if (c->h_ctr->overflow) {
     char msg[160];
-    snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided", (unsigned long long)used,
-             (unsigned long long)hits_cap);
+    snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided",
+             (unsigned long long)(multi_base + c->h_ctr->hit_count), (unsigned long long)hits_cap);
     set_error(msg);
-    if (n_hits_host) *n_hits_host = used;  // what a retry needs
     return SBWT_ERR_CAPACITY;
   }
-  if (n_hits_host) *n_hits_host = used;
   return SBWT_OK;
 }
 
@@ -414,6 +448,58 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
   if (int rc = ensure(&c->d_results, &res_have, n_reads)) return rc;
   c->staged_reads = lens_have < res_have ? lens_have : res_have;
   if (int rc = ensure(&c->d_hits, &c->staged_hits, hits_cap ? hits_cap : 1)) return rc;
+  // Large batches go in sub-batches so that the copy-in of the next one and the copy-out of the previous one run
+  // while one is being mapped (the link, not the kernels, bounds this entry point).  SBWT_SUBBATCH = reads per
+  // sub-batch (0 = never split).
+  uint64_t sub = 2u << 20;
+  if (const char* e = getenv("SBWT_SUBBATCH")) sub = strtoull(e, nullptr, 10);
+  sub = (sub + 63) & ~63ull;  // whole result lines per sub-batch
+  if (sub && n_reads >= 2 * sub && hits_cap >= n_reads && c->s_in && c->s_out) {
+    uint64_t used_multi = 0;
+    bool ok = true;
+    int rc = SBWT_OK;
+    auto copy_in = [&](uint64_t a0, uint64_t n0, int slot) -> hipError_t {
+      hipError_t e = hipMemcpyAsync(c->d_packed + a0 * words_per_read, packed + a0 * words_per_read, n0 * words_per_read * 4,
+                                    hipMemcpyHostToDevice, c->s_in);
+      if (e == hipSuccess) e = hipMemcpyAsync(c->d_lens + a0, lens + a0, n0 * 4, hipMemcpyHostToDevice, c->s_in);
+      if (e == hipSuccess) e = hipEventRecord(c->ev_in[slot], c->s_in);
+      return e;
+    };
+    SBWT_HIP(copy_in(0, std::min(sub, n_reads), 0));
+    int slot = 0;
+    for (uint64_t a0 = 0; a0 < n_reads && ok; a0 += sub, slot ^= 1) {
+      const uint64_t n0 = std::min(sub, n_reads - a0);
+      if (a0 + sub < n_reads) SBWT_HIP(copy_in(a0 + sub, std::min(sub, n_reads - a0 - sub), slot ^ 1));
+      SBWT_HIP(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+      uint64_t mu = 0;
+      // this sub-batch sees hits[] from its first read on: unique hits at its own read indices, lists behind the
+      // slots of ALL reads and the lists of the sub-batches before it
+      rc = map_pass(c, c->d_packed + a0 * words_per_read, c->d_lens + a0, n0, words_per_read, limit, strand,
+                    c->d_results + a0, c->d_hits + a0, hits_cap - a0, (n_reads - a0) + used_multi, &mu, a0 != 0);
+      if (rc != SBWT_OK) { ok = false; break; }
+      if (a0) {
+        k_bias_first_hit<<<grid_items(n0, 256), 256, 0, c->stream>>>(c->d_results + a0, n0, a0);
+        SBWT_LAUNCHED();
+      }
+      SBWT_HIP(hipEventRecord(c->ev_k, c->stream));
+      SBWT_HIP(hipStreamWaitEvent(c->s_out, c->ev_k, 0));
+      SBWT_HIP(hipMemcpyAsync(results + a0, c->d_results + a0, n0 * sizeof(sbwt_read_result), hipMemcpyDeviceToHost, c->s_out));
+      SBWT_HIP(hipMemcpyAsync(hits + a0, c->d_hits + a0, n0 * sizeof(sbwt_hit), hipMemcpyDeviceToHost, c->s_out));
+      if (mu) SBWT_HIP(hipMemcpyAsync(hits + n_reads + used_multi, c->d_hits + n_reads + used_multi, mu * sizeof(sbwt_hit),
+                                      hipMemcpyDeviceToHost, c->s_out));
+      used_multi += mu;
+    }
+    SBWT_HIP(hipStreamSynchronize(c->s_in));
+    SBWT_HIP(hipStreamSynchronize(c->stream));
+    SBWT_HIP(hipStreamSynchronize(c->s_out));
+    if (ok) {
+      c->last_stats[2] = n_reads + used_multi;
+      if (n_hits) *n_hits = n_reads + used_multi;
+      return SBWT_OK;
+    }
+    if (rc != SBWT_ERR_CAPACITY) return rc;
+    // the lists did not fit: the whole batch in one pass below reports what a retry needs
+  }
   SBWT_HIP(hipMemcpyAsync(c->d_packed, packed, words * 4, hipMemcpyHostToDevice, c->stream));
   SBWT_HIP(hipMemcpyAsync(c->d_lens, lens, n_reads * 4, hipMemcpyHostToDevice, c->stream));
   uint64_t nh = 0;

@@ -27,7 +27,7 @@ struct MultiSortArgs {
   int strand;
   sbwt_read_result* results;
   sbwt_hit* hits;
-  uint64_t n_reads;
+  uint64_t multi_base;                   // first slot of hits[] for multi-hit lists (n_reads, unless the caller splits a batch)
   const uint32_t* queue;                 // wave w of the search kernel queued its reads at queue[w * chunk ..)
   const WaveInfo* wave_info;             // after k_multi_plan: prefix sums over waves
   uint32_t n_waves;
@@ -41,7 +41,7 @@ struct MultiSortArgs {
 
 // Turns the per-wave totals of k_search_sm into global offsets: exclusive prefix sums of the hit slots and of the
 // queued reads over waves, the grand totals, and the capacity verdict.  One workgroup.
-__global__ __launch_bounds__(1024) void k_multi_plan(WaveInfo* __restrict__ wi, uint32_t n_waves, uint64_t n_reads,
+__global__ __launch_bounds__(1024) void k_multi_plan(WaveInfo* __restrict__ wi, uint32_t n_waves, uint64_t multi_base,
                                                      uint64_t hits_cap, unsigned long long* total_slots,
                                                      unsigned long long* total_count, unsigned int* overflow) {
   __shared__ uint64_t s_slots[1024];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024) void k_multi_plan(WaveInfo* __restrict__ wi, 
   if (threadIdx.x == 1023) {
     *total_slots = ps;
     *total_count = pc;
-    if (n_reads + ps > hits_cap) *overflow = 1u;
+    if (multi_base + ps > hits_cap) *overflow = 1u;
   }
 }
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
         sbwt_read_result res = a.results[r];
         const uint64_t lo = res.sa_lo, m = res.sa_hi - res.sa_lo;
         const uint32_t L = a.lens[r];
-        res.first_hit += a.n_reads + wi.slots;  // wave-relative until now
+        res.first_hit += a.multi_base + wi.slots;  // wave-relative until now
         if (tid == 0) *s_bad = (m > kCap || no_sort_path) ? 1u : 0u;
         team_sync<T>();
         uint32_t N = 64;

@@ -394,3 +394,34 @@ def test_two_contexts_map_concurrently(sb, loaded, golden_dir):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_host_buffers_in_sub_batches(sb, loaded, golden_dir, monkeypatch):
+    """sbwt_map_batch splits large batches so that copies overlap the kernels (SBWT_SUBBATCH = reads per
+    sub-batch): forced to 128 here, over unique, dead and multi-hit reads, with a capacity retry"""
+    ix, oix = loaded["g2"]
+    seq = genome_text(os.path.join(golden_dir, "g2.fa"))
+    rng = np.random.default_rng(99)
+    reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
+    while len(reads) < 1500:
+        L = int(rng.integers(12, 80))
+        p = int(rng.integers(0, len(seq) - L))
+        s_ = seq[p:p + L]
+        if "N" in s_:
+            continue
+        if rng.random() < 0.5:
+            s_ = s_.translate(COMP)[::-1]
+        if rng.random() < 0.3:
+            k = int(rng.integers(0, L))
+            s_ = s_[:k] + "ACGT"[int(rng.integers(0, 4))] + s_[k + 1:]
+        reads.append(s_)
+    monkeypatch.setenv("SBWT_SUBBATCH", "128")
+    ctx = sb.Context(ix, len(reads))
+    for strand in (2, 0):
+        res, _ = assert_same(sb, ctx, oix, reads, strand=strand)
+    assert (res["nh"] > 1).sum() >= 2                     # multi-hit lists in more than one sub-batch's wake
+    packed, lens = sb.pack_reads(reads)
+    with pytest.raises(sb.SbwtError) as e:                # room for the unique slots only: the lists do not fit
+        ctx.map_batch(packed, lens, hits_cap=len(reads))
+    assert e.value.code == -7
+    ctx.close()
