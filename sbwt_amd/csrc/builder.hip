@@ -882,17 +882,23 @@ extern "C" int sbwt_build_index(const char* fasta_path, const char* prefix_in, u
     FILE* fs = fopen((prefix + "chrStart").c_str(), "wb");
     FILE* fl = fopen((prefix + "chrLen").c_str(), "wb");
     if (!fs || !fl) { if (fs) fclose(fs); if (fl) fclose(fl); set_error("cannot write index files under " + prefix); return SBWT_ERR_IO; }
+    bool ok = true;  // a full disk must not leave truncated side files behind a success status
     for (size_t k = 0; k < G.chr.names.size(); ++k) {
-      fprintf(fs, "%s\t%llu\n", G.chr.names[k].c_str(), (unsigned long long)G.chr.start[k]);
-      fprintf(fl, "%s\t%llu\n", G.chr.names[k].c_str(), (unsigned long long)G.chr_len[k]);
+      ok = ok && fprintf(fs, "%s\t%llu\n", G.chr.names[k].c_str(), (unsigned long long)G.chr.start[k]) > 0;
+      ok = ok && fprintf(fl, "%s\t%llu\n", G.chr.names[k].c_str(), (unsigned long long)G.chr_len[k]) > 0;
     }
-    fclose(fs); fclose(fl);
+    ok = (fclose(fs) == 0) && ok;
+    ok = (fclose(fl) == 0) && ok;
+    if (!ok) { set_error("write error on " + prefix + "chrStart / chrLen"); return SBWT_ERR_IO; }
   }
   if (!write_npos(prefix + "NposLen.z", G.chr.npos_key, G.chr.npos_val, err)) { set_error(err); return SBWT_ERR_IO; }
   uint32_t* d_fwd = nullptr;
   const uint64_t words = (G.g + 15) / 16 + 1;
   SBWT_HIP(hipMalloc(&d_fwd, words * 4));
-  SBWT_HIP(hipMemcpy(d_fwd, G.fwd.data(), words * 4, hipMemcpyHostToDevice));
+  if (hipError_t e = hipMemcpy(d_fwd, G.fwd.data(), words * 4, hipMemcpyHostToDevice)) {
+    (void)hipFree(d_fwd);
+    return hip_fail(e, "hipMemcpy(genome)", __FILE__, __LINE__);
+  }
   sbwt_host_tables* t = nullptr;
   int rc = sbwt_index_build_device(device, d_fwd, G.g, interval, G.chr.start.size(), G.chr.start.data(), nullptr,
                                    G.chr.npos_key.size(), G.chr.npos_key.data(), G.chr.npos_val.data(), nullptr, &t);

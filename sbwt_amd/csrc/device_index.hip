@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unordered_map>
+
 #include "index_impl.hpp"
 #include "rank_device.h"
 
@@ -620,12 +622,12 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   if (int rc = dev_alloc(ix, &sb_abs, n_super * 16)) return rc;
 
   // temporaries
-  uint64_t* chunk_base = nullptr;
-  LayoutErrors* d_err = nullptr;
-  uint64_t* d_small = nullptr;  // [0..1] special, [2..17] k2
-  SBWT_HIP(hipMalloc(&chunk_base, n_chunks * 16 * sizeof(uint64_t)));
-  SBWT_HIP(hipMalloc(&d_err, sizeof(LayoutErrors)));
-  SBWT_HIP(hipMalloc(&d_small, 18 * sizeof(uint64_t)));
+  DevTemp<uint64_t> chunk_base;
+  DevTemp<LayoutErrors> d_err;
+  DevTemp<uint64_t> d_small;  // [0..1] special, [2..17] k2
+  SBWT_HIP(chunk_base.alloc(n_chunks * 16));
+  SBWT_HIP(d_err.alloc(1));
+  SBWT_HIP(d_small.alloc(18));
   SBWT_HIP(hipMemset(d_err, 0, sizeof(LayoutErrors)));
   SBWT_HIP(hipMemset(d_small, 0xff, 2 * sizeof(uint64_t)));
 
@@ -650,14 +652,13 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
              "occ_function mismatches %llu): index files appear to be damaged",
              h_err.loc_fbwt_mismatch, h_err.loc_not_sorted, h_err.occ_mismatch);
     set_error(msg);
-    hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
     return -2;  // SBWT_ERR_FORMAT
   }
 
   {
-    SaCheck* d_chk = nullptr;
+    DevTemp<SaCheck> d_chk;
     SaCheck h_chk;
-    SBWT_HIP(hipMalloc(&d_chk, sizeof(SaCheck)));
+    SBWT_HIP(d_chk.alloc(1));
     SBWT_HIP(hipMemset(d_chk, 0, sizeof(SaCheck)));
     SBWT_HIP(hipMemset(sa_full, 0xff, raw.n * sizeof(uint64_t)));
     if (raw.n_loc) k_sa_fast<<<grid_for(raw.n_loc, 256), 256>>>(d, raw.loc, raw.n_loc, sa_full, d_chk);
@@ -665,7 +666,6 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     k_sa_check<<<grid_for(raw.n, 256), 256>>>(d, sa_full, d_chk);
     SBWT_LAUNCHED();
     SBWT_HIP(hipMemcpy(&h_chk, d_chk, sizeof h_chk, hipMemcpyDeviceToHost));
-    hipFree(d_chk);
     if (h_chk.failed || getenv("SBWT_SLOW_SA")) {
       k_sa_full<<<grid_for(raw.n, 256), 256>>>(d, sa_full);
       SBWT_LAUNCHED();
@@ -674,25 +674,24 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   d.sa_full = sa_full;
   if (raw.n >= (1ull << kPosBits)) {
     set_error("index has 2^40 suffixes or more");
-    hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
     return -4;
   }
   {
     // text-jump tables; sa_full still holds plain positions here (rows never claimed keep run 0 = their
     // position with no run bits; rows holding kNoPosition keep it)
-    unsigned long long* row_tab = nullptr;
+    DevTemp<unsigned long long> row_tab;  // it leaves as pos_lines
     uint32_t* textrc = nullptr;
     const uint64_t n_words = ((raw.n - 1 + 63) / 64) * 4 + 8;  // whole 16-byte pieces + 2 of padding: the comparison reads one piece ahead
     PosLine* pos_lines = nullptr;
     const uint64_t n_lines = (raw.n + kPosPerLine - 1) / kPosPerLine;
     if (int rc = dev_alloc(ix, &textrc, n_words)) return rc;
     if (int rc = dev_alloc(ix, &pos_lines, n_lines)) return rc;
-    SBWT_HIP(hipMalloc(&row_tab, raw.n * sizeof(uint64_t)));  // temporary: it leaves as pos_lines
-    uint8_t* badpos = nullptr;
-    uint64_t* chunk_last = nullptr;
+    SBWT_HIP(row_tab.alloc(raw.n));
+    DevTemp<uint8_t> badpos;
+    DevTemp<uint64_t> chunk_last;
     const uint64_t n_run_chunks = (raw.n + kRunChunk - 1) / kRunChunk;
-    SBWT_HIP(hipMalloc(&badpos, raw.n));
-    SBWT_HIP(hipMalloc(&chunk_last, n_run_chunks * sizeof(uint64_t)));
+    SBWT_HIP(badpos.alloc(raw.n));
+    SBWT_HIP(chunk_last.alloc(n_run_chunks));
     SBWT_HIP(hipMemset(badpos, 0, raw.n));
     SBWT_HIP(hipMemset(row_tab, 0xff, raw.n * sizeof(uint64_t)));
     k_row_scatter<<<grid_for(raw.n, 256), 256>>>(raw.n, sa_full, row_tab, badpos);
@@ -708,7 +707,6 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     k_pos_lines<<<grid_for(n_lines, 256), 256>>>(d, row_tab, textrc, pos_lines, n_lines);
     SBWT_LAUNCHED();
     SBWT_HIP(hipDeviceSynchronize());
-    hipFree(badpos); hipFree(chunk_last); hipFree(row_tab);
     d.pos_lines = pos_lines;
     d.textrc = textrc;
   }
@@ -780,15 +778,14 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       H = 0;
     }
     if (H) {
-      unsigned long long* d_counts = nullptr;
-      SBWT_HIP(hipMalloc(&d_counts, 16));
+      DevTemp<unsigned long long> d_counts;
+      SBWT_HIP(d_counts.alloc(2));
       SBWT_HIP(hipMemset(d_counts, 0, 16));
       SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (8 * kHashSlots)));
       k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, d_counts);
       SBWT_LAUNCHED();
       unsigned long long h_counts[2];
       SBWT_HIP(hipMemcpy(h_counts, d_counts, 16, hipMemcpyDeviceToHost));
-      hipFree(d_counts);
       if (getenv("SBWT_DEBUG"))
         fprintf(stderr, "[sbwt debug] hash table: %llu prefixes stored, %llu left out (bucket full)\n", h_counts[0], h_counts[1]);
       d.hash_tab = htab;
@@ -811,7 +808,6 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     }
   }
   SBWT_HIP(hipDeviceSynchronize());
-  hipFree(chunk_base); hipFree(d_err); hipFree(d_small);
   return 0;
 }
 
@@ -829,6 +825,22 @@ int upload_chr_tables(sbwt_index* ix) {
   ix->d.npos_key = nk;
   ix->d.npos_val = nv;
   ix->d.n_npos = (uint32_t)t.npos_key.size();
+  // upstream compares the chromosome NAMES of a hit's two ends (searcher.hpp:526): equal names are one class
+  ix->d.chr_class = nullptr;
+  std::vector<uint32_t> cls(t.names.size());
+  bool repeated = false;
+  std::unordered_map<std::string, uint32_t> first_of;
+  for (size_t k = 0; k < t.names.size(); ++k) {
+    auto it = first_of.emplace(t.names[k], (uint32_t)k);
+    cls[k] = it.first->second;
+    if (!it.second) repeated = true;
+  }
+  if (repeated) {
+    uint32_t* cc = nullptr;
+    if (int rc = dev_alloc(ix, &cc, cls.size())) return rc;
+    SBWT_HIP(hipMemcpy(cc, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
+    ix->d.chr_class = cc;
+  }
   return 0;
 }
 

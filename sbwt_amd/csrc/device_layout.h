@@ -103,6 +103,7 @@ struct DeviceIndex {
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;
+  const uint32_t* chr_class;  // null unless chromosome names repeat: index of the first chromosome with the same name (upstream compares names, :526)
   const uint64_t* npos_key; const uint64_t* npos_val; uint32_t n_npos;
 };
 

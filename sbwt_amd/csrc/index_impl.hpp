@@ -34,6 +34,20 @@ __device__ __forceinline__ uint64_t global_thread() { return global_block() * bl
 // a failed launch must not go unnoticed until some later call happens to report it
 #define SBWT_LAUNCHED() SBWT_HIP(hipGetLastError())
 
+// device temporary, freed on every way out of its scope (release() frees it early)
+template <typename T>
+struct DevTemp {
+  T* p = nullptr;
+  DevTemp() = default;
+  DevTemp(const DevTemp&) = delete;
+  DevTemp& operator=(const DevTemp&) = delete;
+  ~DevTemp() { release(); }
+  hipError_t alloc(uint64_t count) { return hipMalloc(reinterpret_cast<void**>(&p), (count ? count : 1) * sizeof(T)); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; }
+  operator T*() const { return p; }
+  T* operator->() const { return p; }
+};
+
 // Reference-format tables resident on the device (temporary inputs of the re-layout).
 struct RawDeviceTables {
   uint64_t interval = 0, n = 0, first_location = 0, real_size = 0;

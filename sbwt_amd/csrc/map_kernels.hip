@@ -438,6 +438,12 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
     set_error("sbwt_map_batch: null pointer");
     return SBWT_ERR_ARG;
   }
+  // the same checks as sbwt_map_batch_device, before anything is staged or split: the queues of the ctx hold
+  // max_reads entries whichever way the batch is cut
+  if (n_reads > c->max_reads || words_per_read == 0 || (words_per_read & 3u)) {
+    set_error("sbwt_map_batch: n_reads exceeds the ctx capacity or words_per_read is not a multiple of 4");
+    return SBWT_ERR_ARG;
+  }
   if (n_hits) *n_hits = 0;
   if (n_reads == 0) return SBWT_OK;
   SBWT_HIP(hipSetDevice(c->ix->device));
@@ -458,6 +464,7 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
     uint64_t used_multi = 0;
     bool ok = true;
     int rc = SBWT_OK;
+    hipError_t he = hipSuccess;  // first HIP failure inside the loop: the loop stops, the streams drain, then it is reported
     auto copy_in = [&](uint64_t a0, uint64_t n0, int slot) -> hipError_t {
       hipError_t e = hipMemcpyAsync(c->d_packed + a0 * words_per_read, packed + a0 * words_per_read, n0 * words_per_read * 4,
                                     hipMemcpyHostToDevice, c->s_in);
@@ -465,12 +472,13 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
       if (e == hipSuccess) e = hipEventRecord(c->ev_in[slot], c->s_in);
       return e;
     };
-    SBWT_HIP(copy_in(0, std::min(sub, n_reads), 0));
+    he = copy_in(0, std::min(sub, n_reads), 0);
     int slot = 0;
-    for (uint64_t a0 = 0; a0 < n_reads && ok; a0 += sub, slot ^= 1) {
+    for (uint64_t a0 = 0; a0 < n_reads && ok && he == hipSuccess; a0 += sub, slot ^= 1) {
       const uint64_t n0 = std::min(sub, n_reads - a0);
-      if (a0 + sub < n_reads) SBWT_HIP(copy_in(a0 + sub, std::min(sub, n_reads - a0 - sub), slot ^ 1));
-      SBWT_HIP(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+      if (a0 + sub < n_reads) he = copy_in(a0 + sub, std::min(sub, n_reads - a0 - sub), slot ^ 1);
+      if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, c->ev_in[slot], 0);
+      if (he != hipSuccess) break;
       uint64_t mu = 0;
       // this sub-batch sees hits[] from its first read on: unique hits at its own read indices, lists behind the
       // slots of ALL reads and the lists of the sub-batches before it
@@ -479,19 +487,21 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
       if (rc != SBWT_OK) { ok = false; break; }
       if (a0) {
         k_bias_first_hit<<<grid_items(n0, 256), 256, 0, c->stream>>>(c->d_results + a0, n0, a0);
-        SBWT_LAUNCHED();
+        he = hipGetLastError();
       }
-      SBWT_HIP(hipEventRecord(c->ev_k, c->stream));
-      SBWT_HIP(hipStreamWaitEvent(c->s_out, c->ev_k, 0));
-      SBWT_HIP(hipMemcpyAsync(results + a0, c->d_results + a0, n0 * sizeof(sbwt_read_result), hipMemcpyDeviceToHost, c->s_out));
-      SBWT_HIP(hipMemcpyAsync(hits + a0, c->d_hits + a0, n0 * sizeof(sbwt_hit), hipMemcpyDeviceToHost, c->s_out));
-      if (mu) SBWT_HIP(hipMemcpyAsync(hits + n_reads + used_multi, c->d_hits + n_reads + used_multi, mu * sizeof(sbwt_hit),
-                                      hipMemcpyDeviceToHost, c->s_out));
+      if (he == hipSuccess) he = hipEventRecord(c->ev_k, c->stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(c->s_out, c->ev_k, 0);
+      if (he == hipSuccess) he = hipMemcpyAsync(results + a0, c->d_results + a0, n0 * sizeof(sbwt_read_result), hipMemcpyDeviceToHost, c->s_out);
+      if (he == hipSuccess) he = hipMemcpyAsync(hits + a0, c->d_hits + a0, n0 * sizeof(sbwt_hit), hipMemcpyDeviceToHost, c->s_out);
+      if (he == hipSuccess && mu)
+        he = hipMemcpyAsync(hits + n_reads + used_multi, c->d_hits + n_reads + used_multi, mu * sizeof(sbwt_hit),
+                            hipMemcpyDeviceToHost, c->s_out);
       used_multi += mu;
     }
-    SBWT_HIP(hipStreamSynchronize(c->s_in));
-    SBWT_HIP(hipStreamSynchronize(c->stream));
-    SBWT_HIP(hipStreamSynchronize(c->s_out));
+    // whatever happened, no copy may still be aimed at the caller's buffers when this call returns
+    const hipError_t e1 = hipStreamSynchronize(c->s_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->s_out);
+    if (he == hipSuccess) he = e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3);
+    if (he != hipSuccess) return hip_fail(he, "sbwt_map_batch (sub-batches)", __FILE__, __LINE__);
     if (ok) {
       c->last_stats[2] = n_reads + used_multi;
       if (n_hits) *n_hits = n_reads + used_multi;

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
                 h0 = rev_bases(c0);
                 h1 = rev_bases(c1);
                 py = ((uint64_t)t << 58);
+                if (ok && h.pos0 > kPosMask) *s_bad = 1u;  // (an upstream-accepted wrapped position: the depth-first kernel writes whole hits)
                 if (ok) py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
               }
             }

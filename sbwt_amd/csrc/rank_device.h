@@ -104,8 +104,13 @@ __device__ __forceinline__ uint32_t upper_bound_minus1(const uint64_t* __restric
 }
 
 // searcher.hpp:504-539 for one lane.  chr / npos_key / npos_val are the sorted tables (global memory or a
-// workgroup's LDS copy).  The upstream test "first and last base fall into the same chromosome / the same N-free
-// segment" (upper_bound - 1 of both ends, :519-533) is: no key lies in (position, position + L - 1].
+// workgroup's LDS copy).  Upstream takes upper_bound - 1 of the first and of the last base in both maps (:519-533)
+// and drops the hit when the chromosome NAMES differ or the N-free segments differ.  While position + L - 1 does
+// not wrap that is: no key lies in (position, position + L - 1] (chromosome keys between two chromosomes of the
+// same name excepted: chr_class, set only when names repeat).  It wraps for the false candidates the c_functions
+// table carries -- the up to 11 end-of-text suffixes shorter than 12 sit at the end of the preceding 12-mer's
+// bucket, a hit built on one has p + L > 2 * real_size and `position` underflows (unsigned, as
+// upstream's INTTYPE does) -- and then both ends are looked up as upstream does, on the wrapped values.
 __device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos_key,
                                                    const uint64_t* npos_val, uint64_t position, uint32_t L, int strand,
                                                    sbwt_hit* out) {
@@ -117,9 +122,19 @@ __device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const 
   if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
   const uint64_t last = position + L - 1;
   const uint32_t c1 = upper_bound_minus1(chr, ix.n_chr, position);
-  if (c1 + 1 < ix.n_chr && chr[c1 + 1] <= last) return false;
   const uint32_t n1 = upper_bound_minus1(npos_key, ix.n_npos, position);
-  if (n1 + 1 < ix.n_npos && npos_key[n1 + 1] <= last) return false;
+  if (last >= position) {
+    if (c1 + 1 < ix.n_chr && chr[c1 + 1] <= last) {
+      if (!ix.chr_class) return false;
+      const uint32_t c3 = upper_bound_minus1(chr, ix.n_chr, last);
+      if (ix.chr_class[c1] != ix.chr_class[c3]) return false;
+    }
+    if (n1 + 1 < ix.n_npos && npos_key[n1 + 1] <= last) return false;
+  } else {
+    const uint32_t c3 = upper_bound_minus1(chr, ix.n_chr, last);
+    if (c1 != c3 && (!ix.chr_class || ix.chr_class[c1] != ix.chr_class[c3])) return false;
+    if (n1 != upper_bound_minus1(npos_key, ix.n_npos, last)) return false;
+  }
   out->pos0 = position - chr[c1] + npos_val[n1];
   out->chr_id = c1;
   out->is_rc = is_rc ? 1u : 0u;

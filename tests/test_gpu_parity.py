@@ -425,3 +425,12 @@ def test_host_buffers_in_sub_batches(sb, loaded, golden_dir, monkeypatch):
         ctx.map_batch(packed, lens, hits_cap=len(reads))
     assert e.value.code == -7
     ctx.close()
+    small = sb.Context(ix, 200)                           # a batch beyond the ctx capacity is refused before it is split
+    with pytest.raises(sb.SbwtError) as e:
+        small.map_batch(packed, lens)
+    assert e.value.code == -4
+    with pytest.raises(sb.SbwtError) as e:                # words_per_read must be a multiple of 4
+        small.map_batch(np.zeros((100, 6), np.uint32), np.full(100, 12, np.uint32))
+    assert e.value.code == -4
+    res, _ = assert_same(sb, small, oix, reads[:200])     # and the ctx is still good
+    small.close()
