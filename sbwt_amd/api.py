@@ -1,6 +1,8 @@
 """ctypes binding of include/sbwt_amd.h (one Python wrapper per C entry point, same names)."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -48,6 +50,26 @@ def lib_path():
     return os.path.join(_HERE, "lib", "libsbwt_amd.so")
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's) next to
+    their own HSA runtime.  libsbwt_amd.so needs `libamdhip64.so.7`: loaded after torch it binds to torch's copy (one
+    runtime, fine); loaded BEFORE torch it brings in /opt/rocm's, torch then loads its own by file name, and the
+    second runtime to initialise sees no device.  So when torch is installed and not yet imported, its runtime is
+    loaded here first: whatever the import order, the process ends up with that one copy.
+    SBWT_HIP_RUNTIME=system keeps the system runtime (hosts that never import torch)."""
+    if os.environ.get("SBWT_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Loads libsbwt_amd.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -56,6 +78,7 @@ def lib():
     path = lib_path()
     if not os.path.exists(path):
         raise SbwtError(-3, "%s is missing: run `python -m sbwt_amd.build` (hipcc, gfx950)" % path)
+    _one_hip_runtime()
     L = C.CDLL(path)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     p = C.POINTER

@@ -855,6 +855,7 @@ extern "C" int sbwt_index_build_device(int device, const uint32_t* d_fwd_packed,
     R.disown(R.raw.c_functions);
     int rc = build_device_layout(ix, R.raw);
     if (!rc) rc = upload_chr_tables(ix);
+    if (!rc) rc = finish_index(ix);
     if (rc) {
       delete ix;
       if (out_tables && *out_tables) { sbwt_host_tables_free(*out_tables); *out_tables = nullptr; }

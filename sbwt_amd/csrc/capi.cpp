@@ -99,6 +99,7 @@ static int make_index(int device, uint64_t interval, uint64_t n, uint64_t first_
   }
   if (int rc = build_device_layout(ix.get(), raw)) return rc;
   if (int rc = upload_chr_tables(ix.get())) return rc;
+  if (int rc = finish_index(ix.get())) return rc;
   *out = ix.release();
   return SBWT_OK;
 }

@@ -63,8 +63,15 @@ struct RawDeviceTables {
 
 }  // namespace sbwt
 
+// launch shapes of the mapping kernels for an index on its device (map_kernels.hip: plan_launches)
+struct sbwt_launch_plan {
+  uint32_t grid_sm_lds = 0, grid_sm_glb = 0, grid_sort = 0;
+  size_t sm_lds_bytes = 0, sm_ring_bytes = 0, sort_lds_bytes = 0;
+};
+
 struct sbwt_index {
   int device = 0;
+  sbwt_launch_plan plan;
   sbwt::DeviceIndex d{};
   std::vector<void*> allocs;  // every hipMalloc the index owns
   uint64_t device_bytes = 0;
@@ -78,6 +85,8 @@ namespace sbwt {
 // adopted (not copied).  Runs on the current device, default stream, synchronous.
 int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw);
 int upload_chr_tables(sbwt_index* ix);
+// map_kernels.hip: the launch plan of the index; the last step of every call that creates an index
+int finish_index(sbwt_index* ix);
 template <typename T>
 int dev_alloc(sbwt_index* ix, T** p, uint64_t count) {
   void* q = nullptr;

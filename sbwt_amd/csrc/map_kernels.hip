@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 #include "../../include/sbwt_amd.h"
@@ -144,23 +145,38 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
 // ---------------------------------------------------------------------------------------------------
 using namespace sbwt;
 
-struct sbwt_ctx {
-  const sbwt_index* ix = nullptr;
+// test knobs (tests/test_gpu_rare_paths.py): an environment variable lowers a limit so that small inputs reach
+// the code large ones would
+static uint32_t debug_knob(const char* name, uint32_t dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const unsigned long v = strtoul(e, nullptr, 10);
+  return v < dflt ? (uint32_t)v : dflt;
+}
+
+// What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
+// launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
+// the file-scope scratch array of the device.
+struct MapWork {
   hipStream_t stream = nullptr;
-  uint64_t max_reads = 0;
   Counters* d_ctr = nullptr;
   Counters* h_ctr = nullptr;  // pinned
-  uint32_t* d_queue = nullptr;
-  uint32_t* d_dfs_queue = nullptr;
-  WaveInfo* d_wave_info = nullptr;
-  Frame* d_stacks = nullptr;
+  uint32_t* d_queue = nullptr;      // max_reads entries
+  uint32_t* d_dfs_queue = nullptr;  // max_reads entries
+  WaveInfo* d_wave_info = nullptr;  // one per wave of k_search_sm
+  Frame* d_stacks = nullptr;        // multi_lanes * interval frames
   uint32_t multi_lanes = 0;
   uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // resident workgroups of k_search_sm
   uint32_t grid_sort = 0;                     // ... of k_multi_sort
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
   size_t sort_lds_bytes = 0;                  // filter tables of k_multi_sort in LDS (0: they stay in global memory)
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // null: the pass is not timed
+};
+
+struct sbwt_ctx : MapWork {
+  const sbwt_index* ix = nullptr;
+  uint64_t max_reads = 0;
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
@@ -171,6 +187,32 @@ struct sbwt_ctx {
   sbwt_hit* d_hits = nullptr;
   uint64_t staged_words = 0, staged_reads = 0, staged_hits = 0;
 };
+
+// Launch shapes of the kernels for this index on its device: resident workgroups per kernel variant and the LDS
+// each takes.  Allocates nothing.
+static hipError_t plan_launches(const sbwt_index* ix, MapWork* w) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, ix->device);
+  if (e != hipSuccess) return e;
+  const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
+  const size_t ring_bytes = (size_t)4 * kSmRing * 16;  // four waves per workgroup
+  w->sm_ring_bytes = ring_bytes;
+  w->sm_lds_bytes = 0;
+  w->sort_lds_bytes = 0;
+  const uint32_t max_keys = debug_knob("SBWT_DEBUG_LDS_KEYS", kSmMaxKeys);
+  if (ix->d.n_chr + ix->d.n_npos <= max_keys && n_super <= kSmMaxSuper)
+    w->sm_lds_bytes = (((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super + 1) & ~(size_t)1) * sizeof(uint64_t);
+  int sm_lds = 0, sm_glb = 0, sort_per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true, true>, 256, w->sm_lds_bytes + ring_bytes);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false, true>, 256, ring_bytes);
+  if (ix->d.n_chr + ix->d.n_npos <= max_keys) w->sort_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, w->sort_lds_bytes);
+  if (e != hipSuccess) return e;
+  w->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
+  w->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
+  w->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
+  return hipSuccess;
+}
 
 extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ctx** out) {
   if (!ix || !out || max_reads == 0 || max_reads > 0xffffffffull) {
@@ -196,29 +238,9 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking);
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming);
-  if (e == hipSuccess) {
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, ix->device);
-    const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
-    const size_t ring_bytes = (size_t)4 * kSmRing * 16;  // four waves per workgroup
-    c->sm_ring_bytes = ring_bytes;
-    if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys && n_super <= kSmMaxSuper)
-      c->sm_lds_bytes = (((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos + 16 * n_super + 1) & ~(size_t)1) * sizeof(uint64_t);
-    int sm_lds = 0, sm_glb = 0;
-    if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true, true>, 256, c->sm_lds_bytes + ring_bytes);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false, true>, 256, ring_bytes);
-    int sort_per_cu = 0;
-    if (ix->d.n_chr + ix->d.n_npos <= kSmMaxKeys) c->sort_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, c->sort_lds_bytes);
-    c->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
-    if (e == hipSuccess) {
-      c->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
-      c->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
-    }
-    if (e == hipSuccess)
-      e = hipMalloc(&c->d_wave_info, (size_t)std::max(c->grid_sm_lds, c->grid_sm_glb) * 4 * sizeof(WaveInfo));
-  }
+  if (e == hipSuccess) e = plan_launches(ix, c);
+  if (e == hipSuccess)
+    e = hipMalloc(&c->d_wave_info, (size_t)std::max(c->grid_sm_lds, c->grid_sm_glb) * 4 * sizeof(WaveInfo));
   if (e != hipSuccess) {
     sbwt_ctx_free(c);
     return hip_fail(e, "sbwt_ctx_create", __FILE__, __LINE__);
@@ -273,10 +295,18 @@ __global__ __launch_bounds__(256) void k_bias_first_hit(sbwt_read_result* __rest
 }
 
 // One device pass over n_reads reads.  Unique hits go to d_hits[read index], multi-hit lists to d_hits[multi_base ..)
-// (multi_base = n_reads for a whole batch); *multi_used = slots the lists took.  Synchronises the ctx stream.
+// (multi_base = n_reads for a whole batch); *multi_used = slots the lists took.  Synchronises the stream of `w`.
+// ms (3 floats) / stats (4 counters) may be null; with `accumulate` they are added to.
+static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                    uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate, float* ms_out,
+                    uint64_t* stats_out);
 static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                     uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
-                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate);
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate) {
+  return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, d_results, d_hits, hits_cap, multi_base,
+                  multi_used, accumulate, c->last_ms, c->last_stats);
+}
 
 extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                                      uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results,
@@ -310,9 +340,10 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   return rc;
 }
 
-static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                     uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
-                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate) {
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate, float* ms_out,
+                    uint64_t* stats_out) {
   MapArgs a;
   a.packed = d_packed;
   a.lens = d_lens;
@@ -323,11 +354,12 @@ static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_len
   a.results = d_results;
   a.hits = d_hits;
   a.hits_cap = hits_cap;
-  a.ctr = c->d_ctr;
-  a.multi_queue = c->d_queue;
-  SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
-  SBWT_HIP(hipEventRecord(c->ev[0], c->stream));
-  const DeviceIndex& d = c->ix->d;
+  a.ctr = w.d_ctr;
+  a.multi_queue = w.d_queue;
+  SBWT_HIP(hipMemsetAsync(w.d_ctr, 0, sizeof(Counters), w.stream));
+  const bool timed = w.ev[0] != nullptr;
+  if (timed) SBWT_HIP(hipEventRecord(w.ev[0], w.stream));
+  const DeviceIndex& d = ix->d;
   uint32_t n_waves = 0;
   uint64_t chunk = 0;
   {
@@ -341,27 +373,29 @@ static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_len
     sa.results = d_results;
     sa.hits = d_hits;
     sa.hits_cap = hits_cap;
-    sa.multi_queue = c->d_queue;
-    sa.wave_info = c->d_wave_info;
-    sa.index_accesses = &c->d_ctr->index_accesses;
-    const bool lds = c->sm_lds_bytes != 0;
+    sa.multi_queue = w.d_queue;
+    sa.wave_info = w.d_wave_info;
+    sa.index_accesses = &w.d_ctr->index_accesses;
+    sa.ring_width_max = debug_knob("SBWT_DEBUG_RING_WIDTH", (uint32_t)kRingWidthMax);
+    sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
+    const bool lds = w.sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? c->grid_sm_lds : c->grid_sm_glb);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? w.grid_sm_lds : w.grid_sm_glb);
     // records of more than 64 bases: the variant that holds two 64-base pieces and compares up to 128 bases at once
     const bool long_reads = words_per_read > 4;
-    if (lds && long_reads) k_search_sm<true, true><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
-    else if (lds) k_search_sm<true, false><<<grid, 256, c->sm_lds_bytes + c->sm_ring_bytes, c->stream>>>(d, sa);
-    else if (long_reads) k_search_sm<false, true><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
-    else k_search_sm<false, false><<<grid, 256, c->sm_ring_bytes, c->stream>>>(d, sa);
+    if (lds && long_reads) k_search_sm<true, true><<<grid, 256, w.sm_lds_bytes + w.sm_ring_bytes, w.stream>>>(d, sa);
+    else if (lds) k_search_sm<true, false><<<grid, 256, w.sm_lds_bytes + w.sm_ring_bytes, w.stream>>>(d, sa);
+    else if (long_reads) k_search_sm<false, true><<<grid, 256, w.sm_ring_bytes, w.stream>>>(d, sa);
+    else k_search_sm<false, false><<<grid, 256, w.sm_ring_bytes, w.stream>>>(d, sa);
     SBWT_LAUNCHED();
     n_waves = grid * 4;
     chunk = ((n_reads + n_waves - 1) / n_waves + 63) & ~63ull;  // as k_search_sm splits the batch
   }
-  SBWT_HIP(hipEventRecord(c->ev[1], c->stream));
+  if (timed) SBWT_HIP(hipEventRecord(w.ev[1], w.stream));
   {
     // multi-hit reads: gather + sort where the tables allow it, the upstream depth-first walk for the rest
-    k_multi_plan<<<1, 1024, 0, c->stream>>>(c->d_wave_info, n_waves, multi_base, hits_cap, &c->d_ctr->hit_count,
-                                            &c->d_ctr->multi_count, &c->d_ctr->overflow);
+    k_multi_plan<<<1, 1024, 0, w.stream>>>(w.d_wave_info, n_waves, multi_base, hits_cap, &w.d_ctr->hit_count,
+                                           &w.d_ctr->multi_count, &w.d_ctr->overflow);
     SBWT_LAUNCHED();
     MultiSortArgs ms;
     ms.lens = d_lens;
@@ -369,39 +403,44 @@ static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_len
     ms.results = d_results;
     ms.hits = d_hits;
     ms.multi_base = multi_base;
-    ms.queue = c->d_queue;
-    ms.wave_info = c->d_wave_info;
+    ms.queue = w.d_queue;
+    ms.wave_info = w.d_wave_info;
     ms.n_waves = n_waves;
     ms.chunk = chunk;
-    ms.queue_count = &c->d_ctr->multi_count;
-    ms.overflow = &c->d_ctr->overflow;
-    ms.dfs_queue = c->d_dfs_queue;
-    ms.dfs_count = &c->d_ctr->dfs_count;
-    ms.lds_tables = c->sort_lds_bytes ? 1u : 0u;
-    k_multi_sort<64><<<c->grid_sort, 256, c->sort_lds_bytes, c->stream>>>(d, ms);
-    k_multi_sort<256><<<c->grid_sort, 256, c->sort_lds_bytes, c->stream>>>(d, ms);
+    ms.queue_count = &w.d_ctr->multi_count;
+    ms.overflow = &w.d_ctr->overflow;
+    ms.dfs_queue = w.d_dfs_queue;
+    ms.dfs_count = &w.d_ctr->dfs_count;
+    ms.lds_tables = w.sort_lds_bytes ? 1u : 0u;
+    k_multi_sort<64><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
+    k_multi_sort<256><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
     SBWT_LAUNCHED();
-    k_multi<<<c->multi_lanes / 256, 256, 0, c->stream>>>(d, a, c->d_stacks, c->multi_lanes, c->d_dfs_queue,
-                                                         &c->d_ctr->dfs_count);
+    k_multi<<<w.multi_lanes / 256, 256, 0, w.stream>>>(d, a, w.d_stacks, w.multi_lanes, w.d_dfs_queue, &w.d_ctr->dfs_count);
     SBWT_LAUNCHED();
   }
-  SBWT_HIP(hipEventRecord(c->ev[2], c->stream));
-  SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-  SBWT_HIP(hipStreamSynchronize(c->stream));
+  if (timed) SBWT_HIP(hipEventRecord(w.ev[2], w.stream));
+  SBWT_HIP(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, w.stream));
+  SBWT_HIP(hipStreamSynchronize(w.stream));
   SBWT_HIP(hipGetLastError());
-  float ms[3] = {0, 0, 0};
-  hipEventElapsedTime(&ms[0], c->ev[0], c->ev[2]);
-  hipEventElapsedTime(&ms[1], c->ev[0], c->ev[1]);
-  hipEventElapsedTime(&ms[2], c->ev[1], c->ev[2]);
-  for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + ms[k] : ms[k];
-  c->last_stats[0] = (accumulate ? c->last_stats[0] : 0) + c->h_ctr->index_accesses;
-  c->last_stats[1] = (accumulate ? c->last_stats[1] : 0) + c->h_ctr->multi_count;
-  c->last_stats[3] = (accumulate ? c->last_stats[3] : 0) + c->h_ctr->dfs_count;
-  *multi_used = c->h_ctr->hit_count;
-  if (c->h_ctr->overflow) {
+  if (ms_out) {
+    float ms[3] = {0, 0, 0};
+    if (timed) {
+      hipEventElapsedTime(&ms[0], w.ev[0], w.ev[2]);
+      hipEventElapsedTime(&ms[1], w.ev[0], w.ev[1]);
+      hipEventElapsedTime(&ms[2], w.ev[1], w.ev[2]);
+    }
+    for (int k = 0; k < 3; ++k) ms_out[k] = accumulate ? ms_out[k] + ms[k] : ms[k];
+  }
+  if (stats_out) {
+    stats_out[0] = (accumulate ? stats_out[0] : 0) + w.h_ctr->index_accesses;
+    stats_out[1] = (accumulate ? stats_out[1] : 0) + w.h_ctr->multi_count;
+    stats_out[3] = (accumulate ? stats_out[3] : 0) + w.h_ctr->dfs_count;
+  }
+  *multi_used = w.h_ctr->hit_count;
+  if (w.h_ctr->overflow) {
     char msg[160];
     snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided",
-             (unsigned long long)(multi_base + c->h_ctr->hit_count), (unsigned long long)hits_cap);
+             (unsigned long long)(multi_base + w.h_ctr->hit_count), (unsigned long long)hits_cap);
     set_error(msg);
     return SBWT_ERR_CAPACITY;
   }
@@ -523,5 +562,18 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
   if (nh) SBWT_HIP(hipMemcpyAsync(hits, c->d_hits, nh * sizeof(sbwt_hit), hipMemcpyDeviceToHost, c->stream));
   SBWT_HIP(hipStreamSynchronize(c->stream));
   if (n_hits) *n_hits = nh;
+  return SBWT_OK;
+}
+
+int sbwt::finish_index(sbwt_index* ix) {
+  SBWT_HIP(hipSetDevice(ix->device));
+  MapWork w;
+  SBWT_HIP(plan_launches(ix, &w));
+  ix->plan.grid_sm_lds = w.grid_sm_lds;
+  ix->plan.grid_sm_glb = w.grid_sm_glb;
+  ix->plan.grid_sort = w.grid_sort;
+  ix->plan.sm_lds_bytes = w.sm_lds_bytes;
+  ix->plan.sm_ring_bytes = w.sm_ring_bytes;
+  ix->plan.sort_lds_bytes = w.sort_lds_bytes;
   return SBWT_OK;
 }

@@ -76,6 +76,9 @@ struct SmArgs {
   uint32_t* multi_queue;
   struct WaveInfo* wave_info;
   unsigned long long* index_accesses;  // tally of random index accesses (for the roofline accounting)
+  // what a ring entry holds (kRingWidthMax, 16 bits of chr_id; a test knob lowers them to reach the direct path)
+  uint64_t ring_width_max;
+  uint32_t ring_chr_max;
 };
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       // flags: bits 0..1 and bit 31 are in use
       meta |= ((flags & 3u) << R_FLAGS_SHIFT) | ((flags & kFlagInvalid) ? R_INVALID : 0u);
       const uint64_t width = hi - lo;
-      if (hi < lo || width >= kRingWidthMax || chr_id > 0xFFFFu || payload > kPosMask) {
+      if (hi < lo || width >= a.ring_width_max || chr_id > a.ring_chr_max || payload > kPosMask) {
         sm_emit(a, r, lo, hi, payload, chr_id, meta);  // does not fit a ring entry
         meta = R_DIRECT;
       }
