@@ -105,6 +105,7 @@ def lib():
     L.sbwt_pack_reads.argtypes = [vp, vp, u64, u32, vp, vp, p(u64)]
     L.sbwt_map_batch_device.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_map_batch.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
+    L.sbwt_map_batch_device_static.argtypes = [vp, vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_host_alloc.argtypes = [u64, p(vp)]
     L.sbwt_host_free.argtypes = [vp]
     L.sbwt_host_free.restype = None
@@ -251,6 +252,14 @@ class Index:
         _check(lib().sbwt_map_fastq(self._h, os.fsencode(fastq), os.fsencode(sam), limit, strand, n_threads,
                                     C.byref(st)))
         return list(st)
+
+    def map_batch_device_static(self, d_packed, d_lens, n_reads, wpr, d_results, d_hits, hits_cap, limit=1000,
+                                strand=2, stream=None):
+        """sbwt_map_batch_device_static: device pointers, no ctx, allocates nothing (static scratch of the device)."""
+        nh = C.c_uint64(0)
+        _check(lib().sbwt_map_batch_device_static(self._h, stream, d_packed, d_lens, n_reads, wpr, limit, strand,
+                                                  d_results, d_hits, hits_cap, C.byref(nh)))
+        return nh.value
 
     def close(self):
         if self._h:

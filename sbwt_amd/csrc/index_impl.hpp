@@ -85,7 +85,9 @@ namespace sbwt {
 // adopted (not copied).  Runs on the current device, default stream, synchronous.
 int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw);
 int upload_chr_tables(sbwt_index* ix);
-// map_kernels.hip: the launch plan of the index; the last step of every call that creates an index
+// map_kernels.hip: per-device set-up of the static scratch (sbwt_map_batch_device_static) and the launch plan of
+// the index; the last step of every call that creates an index
+int static_scratch_setup(int device);
 int finish_index(sbwt_index* ix);
 template <typename T>
 int dev_alloc(sbwt_index* ix, T** p, uint64_t count) {

@@ -565,7 +565,55 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
   return SBWT_OK;
 }
 
+// ---- sbwt_map_batch_device_static: the device-pointer entry point for callers that cannot allocate ------------
+// The scratch of the kernels (counters, the two queues, per-wave totals, the depth-first stacks) lives in a
+// file-scope device array instead of buffers a sbwt_ctx allocates.  Every GPU the library runs on holds its own
+// copy of the array until the process ends; all calls on one GPU share it, so calls that overlap on one GPU race.
+namespace sbwt {
+constexpr uint64_t kStaticMaxReads = 1ull << 20;   // reads per call
+constexpr uint32_t kStaticMaxWaves = 8192;         // 256 CUs x 8 resident workgroups x 4 waves
+constexpr uint64_t kStaticStackBytes = 256ull * 1024 * sizeof(Frame);  // 256 lanes at interval 1024, 4096 at 64
+constexpr uint64_t kStaticOffCtr = 0;
+constexpr uint64_t kStaticOffWave = 256;
+constexpr uint64_t kStaticOffQueue = kStaticOffWave + kStaticMaxWaves * sizeof(WaveInfo);
+constexpr uint64_t kStaticOffDfs = kStaticOffQueue + kStaticMaxReads * sizeof(uint32_t);
+constexpr uint64_t kStaticOffStacks = kStaticOffDfs + kStaticMaxReads * sizeof(uint32_t);
+constexpr uint64_t kStaticBytes = kStaticOffStacks + kStaticStackBytes;  // 14.1 MiB
+static_assert(sizeof(Counters) <= 256 && kStaticOffStacks % 256 == 0, "scratch layout");
+}  // namespace sbwt
+
+static __device__ __align__(256) unsigned char scratch[sbwt::kStaticBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each device (the name itself is a host-side stand-in)
+Counters* g_static_hctr[kMaxDevices];       // pinned read-back buffer, one per device
+}  // namespace
+
+// Set-up, once per device, from the calls that create an index on it (the library's init for that device): the
+// device address of the scratch array and a pinned buffer for the counters.  The only allocation of this path
+// happens here, never in the entry point.
+int sbwt::static_scratch_setup(int device) {
+  if (device < 0 || device >= kMaxDevices) return SBWT_OK;  // such a device simply has no static path
+  std::lock_guard<std::mutex> lk(g_static_mutex);
+  if (g_scratch_ptr[device]) return SBWT_OK;
+  SBWT_HIP(hipSetDevice(device));
+  unsigned char* ptr = nullptr;
+  SBWT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+  if (!ptr) {
+    set_error("hipGetSymbolAddress(scratch) returned a null address");
+    return SBWT_ERR_HIP;
+  }
+  Counters* h = nullptr;
+  SBWT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(Counters)));
+  g_static_hctr[device] = h;
+  g_scratch_ptr[device] = ptr;
+  return SBWT_OK;
+}
+
 int sbwt::finish_index(sbwt_index* ix) {
+  if (int rc = static_scratch_setup(ix->device)) return rc;
   SBWT_HIP(hipSetDevice(ix->device));
   MapWork w;
   SBWT_HIP(plan_launches(ix, &w));
@@ -576,4 +624,74 @@ int sbwt::finish_index(sbwt_index* ix) {
   ix->plan.sm_ring_bytes = w.sm_ring_bytes;
   ix->plan.sort_lds_bytes = w.sort_lds_bytes;
   return SBWT_OK;
+}
+
+extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, const uint32_t* d_packed,
+                                            const uint32_t* d_lens, uint64_t n_reads, uint32_t words_per_read, int limit,
+                                            int strand, sbwt_read_result* d_results, sbwt_hit* d_hits, uint64_t hits_cap,
+                                            uint64_t* n_hits_host) {
+  if (!ix || (n_reads && (!d_packed || !d_lens || !d_results)) || (hits_cap && !d_hits)) {
+    set_error("sbwt_map_batch_device_static: null pointer");
+    return SBWT_ERR_ARG;
+  }
+  if (n_reads > kStaticMaxReads) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "sbwt_map_batch_device_static: %llu reads in one call, the static scratch holds %llu at most",
+             (unsigned long long)n_reads, (unsigned long long)kStaticMaxReads);
+    set_error(msg);
+    return SBWT_ERR_ARG;
+  }
+  if (words_per_read == 0 || (words_per_read & 3u)) {
+    set_error("sbwt_map_batch_device_static: words_per_read is not a multiple of 4");
+    return SBWT_ERR_ARG;
+  }
+  if (n_hits_host) *n_hits_host = 0;
+  if (n_reads == 0) return SBWT_OK;
+  if (hits_cap < n_reads) {
+    set_error("hits buffer too small: at least one slot per read is needed");
+    if (n_hits_host) *n_hits_host = n_reads;
+    return SBWT_ERR_CAPACITY;
+  }
+  const int dev = ix->device;
+  unsigned char* base = nullptr;
+  Counters* h_ctr = nullptr;
+  if (dev >= 0 && dev < kMaxDevices) {
+    std::lock_guard<std::mutex> lk(g_static_mutex);
+    base = g_scratch_ptr[dev];
+    h_ctr = g_static_hctr[dev];
+  }
+  if (!base || !h_ctr) {
+    set_error("sbwt_map_batch_device_static: the static scratch of this device was not set up");
+    return SBWT_ERR_HIP;
+  }
+  SBWT_HIP(hipSetDevice(dev));
+  MapWork w;
+  w.stream = static_cast<hipStream_t>(stream);
+  w.d_ctr = reinterpret_cast<Counters*>(base + kStaticOffCtr);
+  w.h_ctr = h_ctr;
+  w.d_wave_info = reinterpret_cast<WaveInfo*>(base + kStaticOffWave);
+  w.d_queue = reinterpret_cast<uint32_t*>(base + kStaticOffQueue);
+  w.d_dfs_queue = reinterpret_cast<uint32_t*>(base + kStaticOffDfs);
+  w.d_stacks = reinterpret_cast<Frame*>(base + kStaticOffStacks);
+  // launch shapes: computed when the index was made (plan_launches allocates nothing, but asks the runtime)
+  w.grid_sm_lds = ix->plan.grid_sm_lds;
+  w.grid_sm_glb = ix->plan.grid_sm_glb;
+  w.grid_sort = ix->plan.grid_sort;
+  w.sm_lds_bytes = ix->plan.sm_lds_bytes;
+  w.sm_ring_bytes = ix->plan.sm_ring_bytes;
+  w.sort_lds_bytes = ix->plan.sort_lds_bytes;
+  if (!w.grid_sort || !w.sm_ring_bytes) {
+    set_error("sbwt_map_batch_device_static: the index carries no launch plan");
+    return SBWT_ERR_HIP;
+  }
+  // the scratch bounds the shapes: waves of the search kernel, lanes of the depth-first kernel
+  w.grid_sm_lds = std::min<uint32_t>(w.grid_sm_lds, kStaticMaxWaves / 4);
+  w.grid_sm_glb = std::min<uint32_t>(w.grid_sm_glb, kStaticMaxWaves / 4);
+  const uint64_t lanes = kStaticStackBytes / (ix->d.interval * sizeof(Frame)) / 256 * 256;  // >= 256: interval <= 1024
+  w.multi_lanes = (uint32_t)std::min<uint64_t>(lanes, (n_reads + 255) / 256 * 256);
+  uint64_t multi_used = 0;
+  const int rc = map_pass(ix, w, d_packed, d_lens, n_reads, words_per_read, limit, strand, d_results, d_hits, hits_cap, n_reads,
+                          &multi_used, false, nullptr, nullptr);
+  if (n_hits_host) *n_hits_host = n_reads + multi_used;  // on SBWT_ERR_CAPACITY: what a retry needs
+  return rc;
 }
