@@ -58,6 +58,8 @@ typedef struct sbwt_index_info {
   uint64_t n_chr, n_npos, n_loc;
   uint64_t device_bytes;   /* HBM held by the device layout */
   int device;
+  uint32_t kmer_order;     /* bases the direct search-prefix table memoises (12 = none: c_functions only) */
+  uint32_t hash_order;     /* bases the hash table of located prefixes covers (0 = none) */
 } sbwt_index_info;
 
 const char *sbwt_last_error(void);

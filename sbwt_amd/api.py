@@ -29,7 +29,8 @@ class ReadResult(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n", C.c_uint64), ("real_size", C.c_uint64), ("interval", C.c_uint64),
                 ("first_location", C.c_uint64), ("n_chr", C.c_uint64), ("n_npos", C.c_uint64),
-                ("n_loc", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int)]
+                ("n_loc", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int),
+                ("kmer_order", C.c_uint32), ("hash_order", C.c_uint32)]
 
 
 class HostTables(C.Structure):

@@ -201,6 +201,8 @@ extern "C" int sbwt_index_get_info(const sbwt_index* ix, sbwt_index_info* info) 
   info->n_loc = ix->n_loc;
   info->device_bytes = ix->device_bytes;
   info->device = ix->device;
+  info->kmer_order = ix->d.kmer_order;
+  info->hash_order = ix->d.hash_order;
   return SBWT_OK;
 }
 

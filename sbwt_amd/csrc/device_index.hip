@@ -731,6 +731,15 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     uint32_t K = kKmer;
     size_t free_b = 0, total_b = 0;
     SBWT_HIP(hipMemGetInfo(&free_b, &total_b));
+    // test knobs (tests/test_gpu_rare_paths.py): a smaller budget than the device reports, in bytes; and the
+    // allocation of either prefix table made to fail as it would on a fragmented or shared device
+    if (const char* e = getenv("SBWT_DEBUG_FREE_BYTES")) {
+      const unsigned long long cap = strtoull(e, nullptr, 10);
+      if (cap < free_b) free_b = (size_t)cap;
+    }
+    const char* fail_alloc = getenv("SBWT_DEBUG_FAIL_TABLE_ALLOC");  // "hash", "kmer" or "both"
+    const bool fail_hash = fail_alloc && (!strcmp(fail_alloc, "hash") || !strcmp(fail_alloc, "both"));
+    const bool fail_kmer = fail_alloc && (!strcmp(fail_alloc, "kmer") || !strcmp(fail_alloc, "both"));
     constexpr uint64_t kKmerHeadroom = 24ull << 30;
     // hash table of located order-20 prefixes (device_layout.h): 1.6 slots per suffix, on indexes of 2^22 suffixes
     // or more when it fits next to an order-16 direct table; SBWT_HASH_ORDER overrides (0 = none)
@@ -773,7 +782,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     // both prefix tables are optional: an allocation that fails (fragmented or shared device memory) leaves the
     // index without that table, slower and with the same results
     uint64_t* htab = nullptr;
-    if (H && dev_alloc(ix, &htab, n_buckets * kHashSlots)) {
+    if (H && (fail_hash || dev_alloc(ix, &htab, n_buckets * kHashSlots))) {
       (void)hipGetLastError();
       H = 0;
     }
@@ -796,7 +805,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     d.kmer_order = K;
     d.kmer_tab = nullptr;
     uint64_t* tab = nullptr;
-    if (K > (uint32_t)kKmer && dev_alloc(ix, &tab, 1ull << (2 * K))) {
+    if (K > (uint32_t)kKmer && (fail_kmer || dev_alloc(ix, &tab, 1ull << (2 * K)))) {
       (void)hipGetLastError();
       K = kKmer;
       d.kmer_order = K;
