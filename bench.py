@@ -5,7 +5,14 @@ Workload (BASELINE.json configs[2]): synthetic genome of 2.94 G non-N bases over
 GRCh38-like lengths and N runs, 100 M error-free 50-bp reads, both strands, resident in HBM.
 One step = one pass of the hot path (sbwt_map_batch_device) over the whole read batch.
 N > 1: one process per GPU, index replicated, each rank maps its own 100 M reads (weak scaling, no
-data-path collective; torch.distributed/RCCL only for the barrier and the max-over-ranks).
+data-path collective; torch.distributed/RCCL only for the barrier and the max-over-ranks).  `--gpus N` without
+a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child processes, before this
+process touches a GPU; under torchrun each process is one rank.
+
+Other workloads (parity-checked side lines, never the headline): --rank-path (no memoised search prefix:
+SBWT_HASH_ORDER=0 SBWT_KMER_ORDER=12, the backward search through rank queries that north_star names),
+--genome repeats (40 % of the bases in diverged repeat families + exact segmental duplications),
+--shuffle-ties (suffix order stopped at sort_len 256 with ties in arbitrary order, as upstream's sort leaves them).
 
 Prints ONE JSON line on rank 0.  torch is plumbing here (device memory for the synthetic inputs,
 barrier); the timed work is the library's HIP kernels behind the C ABI.
@@ -14,7 +21,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -90,6 +99,42 @@ def plant_repeats(torch, dev, codes, g, seed, n_families=2000, max_copies=5000):
     idx = slots[:, None] + torch.arange(30, device=dev)[None, :]
     codes[idx.reshape(-1)] = fam[owner].reshape(-1)
     return slots
+
+
+def plant_repeat_families(torch, dev, codes, g, seed, frac=0.40):
+    """--genome repeats: `frac` of the bases are overwritten by copies of repeat families, every copy carrying its own
+    substitutions (interspersed-repeat-like: 150 families, consensus 300 .. 6,000 bp, divergence 0 .. 15 % per
+    family), plus 40 exact duplications of 2 .. 20 kb in 2 .. 6 copies (ties beyond sort_len for the suffix order).
+    Returns the fraction of bases covered."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    covered = 0
+    fams = []
+    for f in range(150):
+        fams.append((int(rng.integers(300, 6001)), float(rng.choice([0.0, 0.02, 0.05, 0.10, 0.15])), 1.0))
+    for f in range(40):
+        fams.append((int(rng.integers(2000, 20001)), 0.0, 0.0))
+    budget = int(g * frac)
+    share = budget // 150
+    for (ln, div, inter) in fams:
+        copies = max(2, share // ln) if inter else int(rng.integers(2, 7))
+        cons = torch.randint(0, 4, (ln,), dtype=torch.uint8, device=dev, generator=gen)
+        step = max(1, (1 << 26) // ln)
+        for a in range(0, copies, step):
+            k = min(step, copies - a)
+            starts = torch.randint(0, g - ln, (k,), device=dev, generator=gen, dtype=torch.int64)
+            block = cons[None, :].expand(k, ln).clone()
+            if div > 0:
+                mut = torch.rand((k, ln), device=dev, generator=gen) < div
+                delta = torch.randint(1, 4, (k, ln), device=dev, generator=gen, dtype=torch.uint8)
+                block = torch.where(mut, (block + delta) & 3, block)
+            rev = torch.randint(0, 2, (k,), device=dev, generator=gen).bool()
+            block = torch.where(rev[:, None], 3 - block.flip(1), block)
+            idx = starts[:, None] + torch.arange(ln, device=dev)[None, :]
+            codes[idx.reshape(-1)] = block.reshape(-1)
+        covered += copies * ln
+    return covered / g
 
 
 def make_reads(torch, dev, codes, g, n_reads, L, seed, wpr, min_len=None, slots=None, mutate=0.0, origins=None):
@@ -179,6 +224,116 @@ def unpack_reads(packed_np, lens_np):
     return seqs, offsets
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: N fresh child processes, one rank per GPU, started before this process
+    touches a GPU (it never does); rank 0's JSON line is passed through."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()           # counts devices without initialising the GPU (see the task's notes)
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit("bench.py: rank exit codes %s" % codes)
+
+
+def write_fastq(path, host_packed, host_lens, L):
+    """FASTQ text of fixed-length reads, vectorised: @r0000000 / bases / + / IIII"""
+    n = host_lens.size
+    seqs, _ = unpack_reads(host_packed, host_lens)
+    seqs = seqs.reshape(n, L)
+    name_w = 2 + 8
+    rec = np.empty((n, name_w + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(8):
+        rec[:, 2 + 7 - d] = ord("0") + (idx // 10 ** d) % 10
+    o = name_w
+    rec[:, o] = 10; o += 1
+    rec[:, o:o + L] = seqs; o += L
+    rec[:, o] = 10; rec[:, o + 1] = ord("+"); rec[:, o + 2] = 10; o += 3
+    rec[:, o:o + L] = ord("I"); o += L
+    rec[:, o] = 10
+    rec.tofile(path)
+    return rec.nbytes
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_index_from_tables(oracle_lib, tables, chr_start, npos_key, npos_val):
+    T = tables.contents
+    c4 = (C.c_uint64 * 4)(*T.c_function4)
+    cs = np.asarray(chr_start, dtype=np.uint64)
+    nk = np.asarray(npos_key, dtype=np.uint64)
+    nv = np.asarray(npos_val, dtype=np.uint64)
+    h = oracle_lib.lib().sbo_index_wrap(T.interval, T.n, T.first_location, T.real_size, C.addressof(c4), T.c_functions,
+                                        T.occ[0], T.occ[1], T.occ[2], T.occ[3], T.occ_len, T.jbwt_seq, T.fbwt,
+                                        T.location_table, T.n_loc, cs.size, cs.ctypes.data, nk.size, nk.ctypes.data,
+                                        nv.ctypes.data)
+    return oracle_lib.OracleIndex(h, keep=(c4, cs, nk, nv))
+
+
+def cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): 4,641,652-bp genome, 10^6 x 50-bp reads,
+    the oracle with 1 thread and with all cores (what `sbwt map -n 1` / `-n <cores>` time upstream)."""
+    g = 4_641_652
+    codes, packed_genome = make_genome(torch, dev, g, seed=4600000)
+    ix, tables = sbwt_amd.build_index_device(packed_genome.data_ptr(), g, [0], [0, g], [0, 0], interval=64, device=dev.index,
+                                             want_index=True, want_tables=True)
+    wpr = sbwt_amd.words_per_read(50)
+    n = 1_000_000
+    packed, lens = make_reads(torch, dev, codes, g, n, 50, seed=50, wpr=wpr)
+    hp = packed.cpu().numpy().view(np.uint32)
+    hl = lens.cpu().numpy().astype(np.uint32)
+    seqs, offsets = unpack_reads(hp, hl)
+    seqs = np.concatenate([seqs, np.zeros(1, np.uint8)])
+    oix = oracle_index_from_tables(oracle_lib, tables, [0], [0, g], [0, 0])
+    n1 = 200_000
+    t1 = time.perf_counter()
+    oix.map_batch_raw(seqs, offsets, n1, nthreads=1)
+    r1 = n1 / (time.perf_counter() - t1)
+    t1 = time.perf_counter()
+    lo, hi, nh, first, ohits = oix.map_batch_raw(seqs, offsets, n, nthreads=cores)
+    rn = n / (time.perf_counter() - t1)
+    # the GPU on the same million reads (device pass only), and parity
+    ctx = sbwt_amd.Context(ix, n)
+    res = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    hits = torch.empty(2 * n * 16, dtype=torch.uint8, device=dev)
+    ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n, wpr, res.data_ptr(), hits.data_ptr(), 2 * n)
+    ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n, wpr, res.data_ptr(), hits.data_ptr(), 2 * n)
+    ms = ctx.last_timing()[0]
+    g_res = np.frombuffer(res.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
+    same = bool(np.array_equal(g_res["sa_lo"], lo) and np.array_equal(g_res["sa_hi"], hi) and np.array_equal(g_res["nh"], nh))
+    ctx.close(); oix.close(); ix.close()
+    sbwt_amd.host_tables_free(tables)
+    return {"workload": "configs[0]: 4,641,652-bp synthetic genome, 10^6 x 50-bp reads", "oracle_1_thread_reads_per_s": round(r1, 1),
+            "oracle_1_thread_sample": n1, "oracle_all_cores_reads_per_s": round(rn, 1), "cores": cores,
+            "gpu_device_pass_reads_per_s": round(n / (ms * 1e-3), 1), "gpu_identical_to_oracle": same,
+            "reference_binary_reads_per_s": {"-n 1": "3.4e4 - 4.1e4", "-n 8": 2.73e5,
+                                             "source": "BASELINE.md (survey container, other host; not measured here)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,10 +344,24 @@ def main():
     ap.add_argument("--read-len", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end and configs[0] legs")
     ap.add_argument("--min-len", type=int, default=None, help="reads of length min-len..read-len (config 5)")
     ap.add_argument("--mutate", type=float, default=0.0, help="fraction of reads with one substitution")
     ap.add_argument("--repeats", action="store_true", help="plant a repeat family, half of the reads inside it (config 5)")
+    ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="repeats: 40 %% of the bases in diverged repeat families")
+    ap.add_argument("--rank-path", action="store_true", help="no memoised search prefix: backward search through rank queries")
+    ap.add_argument("--shuffle-ties", action="store_true", help="suffix order stopped at sort_len 256, ties in arbitrary order")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])
+        return
+
+    if args.rank_path:
+        os.environ["SBWT_HASH_ORDER"] = "0"
+        os.environ["SBWT_KMER_ORDER"] = "12"
+    if args.shuffle_ties:
+        os.environ["SBWT_DEBUG_SORT_DEPTH"] = "256"
 
     import torch
     import sbwt_amd
@@ -214,15 +383,18 @@ def main():
     lens_chr, g, chr_start, npos_key, npos_val = synth_tables(args.scale)
     codes, packed_genome = make_genome(torch, dev, g, seed=38)
     slots = None
+    repeat_cover = None
+    if args.genome == "repeats":
+        repeat_cover = plant_repeat_families(torch, dev, codes, g, seed=40)
+        packed_genome = repack(torch, dev, codes, g)
     if args.repeats:
         slots = plant_repeats(torch, dev, codes, g, seed=5)
         packed_genome = repack(torch, dev, codes, g)
     torch.cuda.synchronize()
     t_genome = time.time() - t0
 
-    # index: suffix order + tables on the GPU, straight into the HBM layout; rank 0 also exports the
-    # reference-format tables for the CPU baseline leg
-    # the CPU baseline and the oracle spot check run on rank 0 of a single-GPU run only
+    # index: suffix order + tables on the GPU, straight into the HBM layout; rank 0 of a single-GPU run also exports
+    # the reference-format tables for the CPU baseline leg and the oracle spot check
     run_cpu = (world == 1 and not args.no_cpu)
     want_tables = run_cpu
     t0 = time.time()
@@ -235,7 +407,7 @@ def main():
     wpr = sbwt_amd.words_per_read(L)
     n_reads = args.reads
     t0 = time.time()
-    plain = args.min_len is None and slots is None and args.mutate == 0.0
+    plain = args.min_len is None and slots is None and args.mutate == 0.0 and args.genome == "iid"
     origins = [] if (plain and rank == 0) else None
     packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots,
                               mutate=args.mutate, origins=origins)
@@ -246,7 +418,8 @@ def main():
 
     res_bytes = n_reads * 32
     results = torch.empty(res_bytes, dtype=torch.uint8, device=dev)
-    hits_cap = n_reads + (1 << 20) if not args.repeats else 80 * n_reads
+    many_hits = args.repeats or args.genome == "repeats"
+    hits_cap = n_reads + (1 << 20) if not many_hits else int(min(80 * n_reads, 6e9))
     hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
     ctx = sbwt_amd.Context(ix, n_reads)
 
@@ -260,7 +433,7 @@ def main():
 
     def timed_step():
         last["hits"] = step()                # synchronises its own stream before returning
-        kernel_ms.append(ctx.last_timing())
+        kernel_ms.append(ctx.last_timing())  # HIP events on the ctx stream, around the kernels of this step
 
     for _ in range(args.warmup):
         step()
@@ -283,55 +456,55 @@ def main():
     res_np = np.frombuffer(results.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
     mapped = int((res_np["nh"] > 0).sum())
     multi = int(((res_np["sa_hi"] - res_np["sa_lo"]) > 1).sum())
-    # Algorithmic bytes of ONE k_search launch: the search is a chain of random accesses
+    # Algorithmic bytes of ONE k_search_sm launch: the search is a chain of random accesses
     # into index tables far larger than any cache, and HBM serves such an access as one 128-byte line whatever
     # part of it is used, so the unit is the line: 128 B x (index lines the reads of the batch need, counted by
     # the kernel itself: search-prefix entry, two-base blocks, memoised locate, text comparison, final row)
     # + the streamed bytes (read record + length in, result + hit out).
-    stats = ctx.last_stats()
+    stats = ctx.last_stats_ex()
     accesses = int(stats[0])
     streamed = n_reads * (wpr * 4 + 4 + 32) + int(n_hits) * 16
     algo_bytes = 128 * accesses + streamed
     achieved = algo_bytes / (search_ms * 1e-3) / 1e9
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
-    traffic = None
-    requests = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # from the PMC passes of tools/profile_final.sh
+    # the random-access roofline of THIS device, measured in this process over the index's own largest table
+    probe = {}
+    for cpl in (1, 2, 4):
+        rate, pbytes = ix.probe_random_access(chains_per_lane=cpl, chain_len=64, workgroups_per_cu=8)
+        probe["%d_chains_per_lane" % cpl] = round(rate / 1e9, 2)
+    gather_peak = max(probe.values())
+    lines_per_s = accesses / (search_ms * 1e-3) / 1e9
+    stored = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes of an earlier run (another box): context only
     if os.path.exists(tpath):
         t = json.load(open(tpath))
-        if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9:
-            traffic = t.get("traffic_GB_per_launch")
-            if t.get("TCC_EA0_RDREQ") and t.get("TCC_EA0_WRREQ"):
-                requests = t["TCC_EA0_RDREQ"] + t["TCC_EA0_WRREQ"]
+        if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9 and plain \
+                and not args.rank_path:
+            stored = {"source": "profiles/traffic.json (rocprofv3 --pmc passes of an earlier run on another box; NOT measured in this run)",
+                      "traffic_GB_per_launch": t.get("traffic_GB_per_launch"),
+                      "hbm_requests_per_launch": (t.get("TCC_EA0_RDREQ", 0) + t.get("TCC_EA0_WRREQ", 0)) or None}
     roofline = {"bound": "hbm", "kernel": "k_search_sm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/traffic.json)",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
                 "launch_ms": round(search_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
                 "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
-                "index_lines_per_s_G": round(accesses / (search_ms * 1e-3) / 1e9, 2),
-                "gather_roofline_lines_per_s_G": 47.0,
-                # HBM requests per launch (PMC, profiles/traffic.json) over this run's launch time, against the
-                # measured random-access roofline of 47 G requests/s (profiles/r1/gather_probe*.txt)
-                "hbm_requests_per_s_G": round(requests / (search_ms * 1e-3) / 1e9, 2) if requests else None,
-                "gather_roofline_frac": round(requests / (search_ms * 1e-3) / 47e9, 3) if requests else None,
+                "index_lines_per_s_G": round(lines_per_s, 2),
+                "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
+                                    "table_GB": round(pbytes / 1e9, 1), "by_chains_per_lane": probe, "peak": gather_peak,
+                                    "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3)},
+                "hash_lookups_per_read": round(stats[4] / n_reads, 4), "hash_hit_rate": round(stats[5] / stats[4], 4) if stats[4] else None,
+                "stored_pmc": stored,
                 "survey_formula_GBps": round(survey_per_read * n_reads / (search_ms * 1e-3) / 1e9, 1)}
 
     cpu = None
     parity = None
+    end_to_end = None
+    config1 = None
+    cores = min(16, os.cpu_count() or 1)
     if run_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
-        T = tables.contents
-        L_ = oracle_lib.lib()
-        c4 = (C.c_uint64 * 4)(*T.c_function4)
-        cs = np.asarray(chr_start, dtype=np.uint64)
-        nk = np.asarray(npos_key, dtype=np.uint64)
-        nv = np.asarray(npos_val, dtype=np.uint64)
-        h = L_.sbo_index_wrap(T.interval, T.n, T.first_location, T.real_size, C.addressof(c4), T.c_functions, T.occ[0],
-                              T.occ[1], T.occ[2], T.occ[3], T.occ_len, T.jbwt_seq, T.fbwt, T.location_table, T.n_loc,
-                              cs.size, cs.ctypes.data, nk.size, nk.ctypes.data, nv.ctypes.data)
-        oix = oracle_lib.OracleIndex(h)
-        cores = min(16, os.cpu_count() or 1)
-        probe_n = 20000
+        oix = oracle_index_from_tables(oracle_lib, tables, chr_start, npos_key, npos_val)
+        probe_n = int(min(20000, n_reads))
         sample_max = 8_000_000
         host_packed = packed[:sample_max].cpu().numpy().view(np.uint32)
         host_lens = lens[:sample_max].cpu().numpy().astype(np.uint32)
@@ -351,30 +524,79 @@ def main():
             oi = (np.repeat(first, nh) + within).astype(np.int64)
             ok = bool(np.array_equal(ghits, ohits[oi]))
         parity = {"reads_checked": probe_n, "identical": ok}
-        sample_n = int(min(sample_max, max(probe_n, rate1 * cores * args.cpu_seconds * 0.7)))
+        sample_n = int(min(sample_max, host_lens.size, max(probe_n, rate1 * cores * args.cpu_seconds * 0.7)))
         seqs, offsets = unpack_reads(host_packed[:sample_n], host_lens[:sample_n])
         t1 = time.perf_counter()
         oix.map_batch_raw(np.concatenate([seqs, np.zeros(1, np.uint8)]), offsets, sample_n, nthreads=cores)
         dt = time.perf_counter() - t1
-        cpu = {"value": round(sample_n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(sample_n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+               "host_cpus": os.cpu_count(),
                "sample": "first %d reads of the same batch, same index (reference-format tables), %d threads; "
-                         "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n)}
+                         "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n),
+               "note": "the port is about 2x the reference binary per thread (7.9e4 vs 3.4-4.1e4 reads/s on configs[0] in the "
+                       "survey container, SURVEY.md section 6): it is a baseline beside the kernel, not the target"}
         oix.close()
         sbwt_amd.host_tables_free(tables)
+        if not args.no_extras and args.min_len is None:
+            # end to end, measured in this run (never `value`): (a) host buffers in, host buffers out through
+            # page-locked memory (PCIe both ways), (b) FASTQ file -> SAM file with 16 host threads
+            from sbwt_amd import api
+            n_e = int(min(n_reads, 16_000_000))
+            pin = api.PinnedBuffer(n_e * (wpr * 4 + 4 + 32 + 2 * 16))
+            o = 0
+            pk = pin.array(np.uint32, n_e * wpr, o); o += n_e * wpr * 4
+            ln = pin.array(np.uint32, n_e, o); o += n_e * 4
+            rs = pin.array(api.RESULT_DTYPE, n_e, o); o += 32 * n_e
+            ht = pin.array(api.HIT_DTYPE, 2 * n_e, o)
+            pk[:] = packed[:n_e].cpu().numpy().view(np.uint32).reshape(-1)
+            ln[:] = lens[:n_e].cpu().numpy().astype(np.uint32)
+            ctx_e = sbwt_amd.Context(ix, n_e)
+            best = None
+            if not many_hits:
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ctx_e.map_batch(pk.reshape(n_e, wpr), ln, out=(rs, ht))
+                    dt = time.perf_counter() - t1
+                    best = dt if best is None or dt < best else best
+            n_f = int(min(n_e, 8_000_000))
+            tmpd = tempfile.mkdtemp(prefix="sbwt_bench_")
+            fq, sam = os.path.join(tmpd, "r.fq"), os.path.join(tmpd, "o.sam")
+            fq_bytes = write_fastq(fq, pk.reshape(n_e, wpr)[:n_f], ln[:n_f], L)
+            fbest = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                st = ix.map_fastq(fq, sam, n_threads=cores)
+                dt = time.perf_counter() - t1
+                fbest = dt if fbest is None or dt < fbest else fbest
+            sam_bytes = os.path.getsize(sam)
+            del pk, ln, rs, ht
+            ctx_e.close()
+            pin.close()
+            shutil.rmtree(tmpd, ignore_errors=True)
+            end_to_end = {"host_buffers_reads_per_s": round(n_e / best, 1) if best else None, "host_buffers_reads": n_e,
+                          "host_buffers_note": "sbwt_map_batch, page-locked host buffers: H2D of packed reads, kernels, D2H of results + hits",
+                          "fastq_to_sam_reads_per_s": round(n_f / fbest, 1), "fastq_to_sam_reads": n_f, "host_threads": cores,
+                          "fastq_MB": round(fq_bytes / 1e6), "sam_MB": round(sam_bytes / 1e6), "sam_records": int(st[4])}
+        if not args.no_extras and plain and args.scale == 1.0:
+            config1 = cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores)
 
+    workload_genome = "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s%s)" % (
+        g / 1e9, ", planted repeat family" if args.repeats else "",
+        ", %.0f %% of the bases in diverged repeat families + exact duplications" % (100 * repeat_cover) if repeat_cover else "")
     line = {
         "metric": "mapped reads/sec (50bp exact, GRCh38) at 1/8 GPUs; achieved HBM GB/s",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s), %d x %s reads per GPU, "
-                               "both strands, -m 1000 -s 2, inputs resident in HBM"
-                               % (g / 1e9, ", planted repeat family" if args.repeats else "", n_reads,
+        "config": {"workload": "%s, %d x %s reads per GPU, both strands, -m 1000 -s 2, inputs resident in HBM"
+                               % (workload_genome, n_reads,
                                   ("%d-bp" % L if args.min_len is None else "%d..%d-nt" % (args.min_len, L))
                                   + (" (%.0f%% with one substitution)" % (100 * args.mutate) if args.mutate else " exact")),
                    "index_suffixes": int(info.n), "index_hbm_GB": round(info.device_bytes / 1e9, 2),
+                   "search_prefix_tables": {"direct_order": int(info.kmer_order), "hash_order": int(info.hash_order)},
+                   "suffix_order": "stopped at sort_len 256, ties shuffled" if args.shuffle_ties else "full",
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": config1,
         "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "hits": int(n_hits),
                    "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
                    "setup_s": {"genome": round(t_genome, 1), "index_build": round(t_index, 1), "reads": round(t_reads, 1)},

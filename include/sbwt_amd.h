@@ -185,6 +185,17 @@ int sbwt_ctx_last_timing(const sbwt_ctx *ctx, float ms[3]);
  * (one per 128-byte line of an index table; the unit of the gather roofline), [1] reads handed to
  * the multi-hit locate, [2] hit slots in use, [3] multi-hit reads that needed the depth-first walk.  No upstream counterpart: measurement only. */
 int sbwt_ctx_last_stats(const sbwt_ctx *ctx, uint64_t stats[4]);
+/* The same and more: the first n counters of [0..3] as above, [4] hash_tab lookups the search kernel made, [5] those
+ * that found their search prefix in it (the hash hit rate of a workload); counters beyond the ones the
+ * library knows read 0. */
+int sbwt_ctx_last_stats_ex(const sbwt_ctx *ctx, uint64_t *stats, uint32_t n);
+/* The random-access roofline of the device, measured over the index's own largest table ("a random
+ * granule gather microbenchmark over a table of the same footprint on the same GPU"): every lane walks
+ * chains_per_lane (1, 2 or 4) chains of chain_len dependent 16-byte loads at pseudo-random 128-byte lines;
+ * workgroups_per_cu workgroups of 256 lanes per CU (0 = 8).  *accesses_per_s = line accesses per second (best of
+ * three launches), *table_bytes (may be NULL) the footprint probed.  No upstream counterpart: measurement only. */
+int sbwt_probe_random_access(const sbwt_index *ix, uint32_t chains_per_lane, uint32_t chain_len,
+                             uint32_t workgroups_per_cu, double *accesses_per_s, uint64_t *table_bytes);
 /* raw hipStream_t of the ctx, for callers that want to order their own work after a batch */
 void *sbwt_ctx_stream(const sbwt_ctx *ctx);
 

@@ -112,6 +112,8 @@ def lib():
     L.sbwt_host_free.restype = None
     L.sbwt_ctx_last_timing.argtypes = [vp, p(C.c_float * 3)]
     L.sbwt_ctx_last_stats.argtypes = [vp, p(u64 * 4)]
+    L.sbwt_ctx_last_stats_ex.argtypes = [vp, p(u64 * 8), u32]
+    L.sbwt_probe_random_access.argtypes = [vp, u32, u32, u32, p(C.c_double), p(u64)]
     L.sbwt_ctx_stream.argtypes = [vp]
     L.sbwt_ctx_stream.restype = vp
     L.sbwt_map_fastq.argtypes = [vp, C.c_char_p, C.c_char_p, i32, i32, i32, p(u64 * 5)]
@@ -245,6 +247,13 @@ class Index:
         _check(lib().sbwt_index_get_info(self._h, C.byref(i)))
         return i
 
+    def probe_random_access(self, chains_per_lane=1, chain_len=64, workgroups_per_cu=8):
+        """sbwt_probe_random_access -> (line accesses per second, bytes of the table probed)"""
+        rate, nbytes = C.c_double(0.0), C.c_uint64(0)
+        _check(lib().sbwt_probe_random_access(self._h, chains_per_lane, chain_len, workgroups_per_cu, C.byref(rate),
+                                              C.byref(nbytes)))
+        return rate.value, nbytes.value
+
     def chr_names(self):
         return [lib().sbwt_index_chr_name(self._h, k).decode() for k in range(self.info().n_chr)]
 
@@ -324,6 +333,11 @@ class Context:
     def last_stats(self):
         st = (C.c_uint64 * 4)()
         _check(lib().sbwt_ctx_last_stats(self._h, C.byref(st)))
+        return list(st)
+
+    def last_stats_ex(self):
+        st = (C.c_uint64 * 8)()
+        _check(lib().sbwt_ctx_last_stats_ex(self._h, C.byref(st), 8))
         return list(st)
 
     def close(self):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsbwt_amd.so")
 BIN = os.path.join(HERE, "bin", "sbwt")
-SOURCES = ["capi.cpp", "index_file.cpp", "host_pipeline.cpp", "device_index.hip", "map_kernels.hip", "builder.hip"]
+SOURCES = ["capi.cpp", "index_file.cpp", "host_pipeline.cpp", "device_index.hip", "map_kernels.hip", "builder.hip", "probe.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-pthread"]
 
 

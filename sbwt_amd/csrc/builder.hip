@@ -116,6 +116,14 @@ __global__ __launch_bounds__(256) void k_keys(Text T, const uint64_t* __restrict
   if (t < cnt) keys[t] = key5(T, pos[t] + off);
 }
 
+__global__ __launch_bounds__(256) void k_hash_keys(const uint64_t* __restrict__ pos, uint64_t cnt, uint64_t* __restrict__ keys) {
+  const uint64_t t = global_thread();
+  if (t >= cnt) return;
+  uint64_t z = pos[t] + 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  keys[t] = z ^ (z >> 31);
+}
 __global__ __launch_bounds__(256) void k_iota64(uint64_t* a, uint64_t cnt) {
   const uint64_t t = global_thread();
   if (t < cnt) a[t] = t;
@@ -383,10 +391,22 @@ struct PartitionSorter {
     return 0;
   }
 
+  // Test knob SBWT_DEBUG_SORT_DEPTH=<bases>: stop the refinement that deep (rounded up to whole 27-base keys) and
+  // leave the suffixes that still tie in a pseudo-random order, as upstream's depth-limited quicksort leaves its
+  // ties beyond sort_len in no particular order (PSEUDO_DCS_FOR_SBWT::compare == true, difference_cover.hpp:30-41).
+  uint64_t max_depth = (uint64_t)kMaxDepth;
+  bool shuffle_ties = false;
+
   // pos_a holds the partition's positions on entry
   int run(const Text& T, uint64_t cnt, uint64_t* sa_part) {
     if (cnt == 0) return 0;
     const dim3 g = blocks_for(cnt);
+    if (shuffle_ties) {
+      // the first sort is stable: ties come out in the order the positions go in, so mix that order first
+      k_hash_keys<<<g, 256>>>(pos_a.p, cnt, key_a.p);
+      if (int rc = sort_pairs(tmp, key_a.p, key_b.p, pos_a.p, pos_b.p, cnt, 64)) return rc;
+      SBWT_HIP(hipMemcpyAsync(pos_a.p, pos_b.p, cnt * 8, hipMemcpyDeviceToDevice, 0));
+    }
     k_keys<<<g, 256>>>(T, pos_a.p, cnt, 0, key_a.p);
     if (int rc = sort_pairs(tmp, key_a.p, key_b.p, pos_a.p, pos_b.p, cnt, 63)) return rc;
     // sorted: key_b / pos_b.  Everything is one group (gid = null); find runs of equal keys.
@@ -401,7 +421,7 @@ struct PartitionSorter {
     uint64_t ns = 0;
     SBWT_HIP(hipMemcpy(&ns, d_count.p, 8, hipMemcpyDeviceToHost));
     // subset: pos_a (positions), u0 (gid)
-    for (uint64_t off = kDigits; ns > 0 && off < (uint64_t)kMaxDepth; off += kDigits) {
+    for (uint64_t off = kDigits; ns > 0 && off < max_depth; off += kDigits) {
       const dim3 gs = blocks_for(ns);
       k_keys<<<gs, 256>>>(T, pos_a.p, ns, off, key_a.p);            // key_a = next 27 digits (subset order)
       k_iota<<<gs, 256>>>(u1.p, ns);
@@ -500,6 +520,13 @@ static int build_raw_tables(const uint32_t* d_fwd, uint64_t g, uint64_t interval
   uint64_t base = 0;
   {
     PartitionSorter S;
+    if (const char* e = getenv("SBWT_DEBUG_SORT_DEPTH")) {
+      const uint64_t want = strtoull(e, nullptr, 10);
+      if (want >= 1 && want < (uint64_t)kMaxDepth) {
+        S.max_depth = (want + kDigits - 1) / kDigits * kDigits;
+        S.shuffle_ties = true;
+      }
+    }
     if (int rc = S.reserve(max_part)) return rc;
     std::vector<uint64_t> slab_off(n_slab, 0);  // where the next partition starts inside each slab
     for (uint32_t v = 0; v < n_part; ++v) {

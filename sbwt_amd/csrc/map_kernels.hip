@@ -34,6 +34,7 @@ struct Counters {
   unsigned int pad0;
   unsigned long long index_accesses;  // random index accesses k_search_sm issued (one per 128-byte line it needs)
   unsigned long long dfs_count;       // multi-hit reads k_multi_sort handed on to the depth-first kernel
+  unsigned long long hash_stats[2];   // hash_tab lookups of k_search_sm, and those that found their prefix
 };
 
 struct MapArgs {
@@ -157,6 +158,8 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
+constexpr int kNumStats = 6;  // sbwt_ctx_last_stats_ex
+
 struct MapWork {
   hipStream_t stream = nullptr;
   Counters* d_ctr = nullptr;
@@ -180,7 +183,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[4] = {0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -282,6 +285,12 @@ extern "C" int sbwt_ctx_last_stats(const sbwt_ctx* c, uint64_t stats[4]) {
   return SBWT_OK;
 }
 
+extern "C" int sbwt_ctx_last_stats_ex(const sbwt_ctx* c, uint64_t* stats, uint32_t n) {
+  if (!c || (!stats && n)) return SBWT_ERR_ARG;
+  for (uint32_t k = 0; k < n; ++k) stats[k] = k < (uint32_t)kNumStats ? c->last_stats[k] : 0;
+  return SBWT_OK;
+}
+
 extern "C" int sbwt_ctx_last_timing(const sbwt_ctx* c, float ms[3]) {
   if (!c || !ms) return SBWT_ERR_ARG;
   for (int k = 0; k < 3; ++k) ms[k] = c->last_ms[k];
@@ -376,6 +385,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     sa.multi_queue = w.d_queue;
     sa.wave_info = w.d_wave_info;
     sa.index_accesses = &w.d_ctr->index_accesses;
+    sa.hash_stats = w.d_ctr->hash_stats;
     sa.ring_width_max = debug_knob("SBWT_DEBUG_RING_WIDTH", (uint32_t)kRingWidthMax);
     sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
     const bool lds = w.sm_lds_bytes != 0;
@@ -435,6 +445,8 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     stats_out[0] = (accumulate ? stats_out[0] : 0) + w.h_ctr->index_accesses;
     stats_out[1] = (accumulate ? stats_out[1] : 0) + w.h_ctr->multi_count;
     stats_out[3] = (accumulate ? stats_out[3] : 0) + w.h_ctr->dfs_count;
+    stats_out[4] = (accumulate ? stats_out[4] : 0) + w.h_ctr->hash_stats[0];
+    stats_out[5] = (accumulate ? stats_out[5] : 0) + w.h_ctr->hash_stats[1];
   }
   *multi_used = w.h_ctr->hit_count;
   if (w.h_ctr->overflow) {

@@ -76,6 +76,7 @@ struct SmArgs {
   uint32_t* multi_queue;
   struct WaveInfo* wave_info;
   unsigned long long* index_accesses;  // tally of random index accesses (for the roofline accounting)
+  unsigned long long* hash_stats;      // [0] hash_tab lookups, [1] lookups that found their prefix (measurement only)
   // what a ring entry holds (kRingWidthMax, 16 bits of chr_id; a test knob lowers them to reach the direct path)
   uint64_t ring_width_max;
   uint32_t ring_chr_max;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   bool reserve = false;
   uint64_t flushed = range_begin;  // wave-uniform: results of reads below it are in global memory
   uint32_t tally = 0;              // random index accesses this lane needed (128-byte lines)
+  uint32_t tally_h = 0;            // hash_tab lookups (high half) and hits (low half) of this lane
   uint64_t wave_slots = 0;  // wave-uniform: hit slots handed to the multi-hit reads of this wave so far
   uint32_t wave_multi = 0;  // wave-uniform: how many such reads
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0, mL = 0, pf = 0;
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       for (int q = 0; q < 4; ++q)
         if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) found = u64_of(sl_lo[q], sl_hi[q]);
       pf = (pf | PF_H1) & ~PF_RH1;
+      tally_h += 0x10000u + (found != ~0ull ? 1u : 0u);
       if (found != ~0ull) {
         const uint64_t run = (found & 0xFFFFFFull) >> ix.hash_tag_bits;
         nk = kKmerLocated | (found >> 24) | (run << kPosBits);
@@ -811,6 +814,11 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     uint32_t t = tally;
     for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
     if (lane == 0) atomicAdd(a.index_accesses, (unsigned long long)t);
+    if (H) {  // wave-uniform
+      uint32_t q = tally_h >> 16, h = tally_h & 0xFFFFu;
+      for (int d = 32; d > 0; d >>= 1) { q += __shfl_xor(q, d); h += __shfl_xor(h, d); }
+      if (lane == 0) { atomicAdd(a.hash_stats, (unsigned long long)q); atomicAdd(a.hash_stats + 1, (unsigned long long)h); }
+    }
   }
   // what is left in the ring
   for (; flushed < range_end; flushed += 64) sm_flush(a, ring, range_begin, flushed + lane, flushed + lane < range_end);

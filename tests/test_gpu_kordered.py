@@ -125,3 +125,74 @@ def test_tie_shuffled_index_matches_oracle(golden_dir, oracle, k, seed):
         assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d" % r
     assert (nh > 0).sum() > len(reads) // 3
     ctx.close(); ix.close(); oix.close()
+
+
+@pytest.mark.parametrize("depth", [27, 54])
+def test_gpu_builder_stopped_at_a_depth_leaves_shuffled_ties(golden_dir, oracle, monkeypatch, depth):
+    """SBWT_DEBUG_SORT_DEPTH: the GPU builder stops refining at `depth` bases and leaves ties in arbitrary order (what
+    bench.py --shuffle-ties runs at GRCh38 scale with depth 256).  The tables it exports must differ from the fully
+    sorted ones inside the 300-bp repeat, and the mapper must still agree with the oracle on those same tables."""
+    import sbwt_amd as sb
+    from test_gpu_scale import pack_codes
+    chroms, fwd = genome(golden_dir)
+    codes = np.array(["ACGT".index(ch) for ch in fwd], dtype=np.uint8)
+    sb.device_count()
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    host = np.concatenate([pack_codes(codes), np.zeros(4, np.uint32)])
+    d_fwd = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_fwd), host.nbytes) == 0
+    assert hip.hipMemcpy(d_fwd, host.ctypes.data, host.nbytes, 1) == 0
+    chr_start = np.array([0, len(chroms[0].replace("N", ""))], dtype=np.uint64)
+    npos_key = np.array([0, 3600, 3720, 6820], dtype=np.uint64)
+    npos_val = np.array([0, 10, 5, 5], dtype=np.uint64)
+    g = len(fwd)
+    _, full = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, want_index=False, want_tables=True)
+    n = full.contents.n
+    fbwt_full = np.ctypeslib.as_array(C.cast(full.contents.fbwt, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    sb.host_tables_free(full)
+    monkeypatch.setenv("SBWT_DEBUG_SORT_DEPTH", str(depth))
+    monkeypatch.setenv("SBWT_KMER_ORDER", "14")
+    monkeypatch.setenv("SBWT_HASH_ORDER", "19")
+    ix, tables = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, want_index=True, want_tables=True,
+                                       chr_names=["chr1", "chr2"])
+    hip.hipFree(d_fwd)
+    T = tables.contents
+    fbwt = np.ctypeslib.as_array(C.cast(T.fbwt, C.POINTER(C.c_uint8)), shape=(n,))
+    assert 0 < (fbwt != fbwt_full).sum() < n // 4          # ties exist and were left in another order; the rest is sorted
+    c4 = (C.c_uint64 * 4)(*T.c_function4)
+    h = oracle.lib().sbo_index_wrap(T.interval, T.n, T.first_location, T.real_size, C.addressof(c4), T.c_functions,
+                                    T.occ[0], T.occ[1], T.occ[2], T.occ[3], T.occ_len, T.jbwt_seq, T.fbwt,
+                                    T.location_table, T.n_loc, 2, chr_start.ctypes.data, 4, npos_key.ctypes.data,
+                                    npos_val.ctypes.data)
+    oix = oracle.OracleIndex(h, keep=(c4, chr_start, npos_key, npos_val))
+    rng = np.random.default_rng(depth)
+    reads = []
+    for Lr in (12, 16, 20, 27, 28, 40, 54, 55, 64, 100, 150):
+        for _ in range(80):
+            p = int(rng.integers(0, g - Lr))
+            s = fwd[p:p + Lr]
+            if rng.random() < 0.5:
+                s = s.translate(COMP)[::-1]
+            if rng.random() < 0.3:
+                q = int(rng.integers(0, Lr))
+                s = s[:q] + "ACGT"[int(rng.integers(0, 4))] + s[q + 1:]
+            reads.append(s)
+    rep = chroms[0][1000:1300]
+    for a, b in ((0, 12), (0, 100), (5, 90), (100, 160), (150, 300), (280, 300), (0, 300), (20, 290), (30, 60), (31, 59)):
+        reads += [rep[a:b], rep[a:b].translate(COMP)[::-1]]
+    packed, lens = sb.pack_reads(reads)
+    ctx = sb.Context(ix, len(reads))
+    res, hits = ctx.map_batch(packed, lens)
+    lo, hi, nh, first, ohits = oix.map_batch(reads)
+    np.testing.assert_array_equal(res["sa_lo"], lo)
+    np.testing.assert_array_equal(res["sa_hi"], hi)
+    np.testing.assert_array_equal(res["nh"], nh)
+    for r in np.nonzero(nh)[0]:
+        a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
+        assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d" % r
+    assert (nh >= 3).sum() >= 6
+    ctx.close(); ix.close(); oix.close()
+    sb.host_tables_free(tables)
