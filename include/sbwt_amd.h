@@ -50,6 +50,40 @@ typedef struct sbwt_read_result {
 #define SBWT_RF_SUPPRESSED 1u /* raw interval larger than `limit` (searcher.hpp:415) */
 #define SBWT_RF_TRUNCATED 2u  /* more pushes than raw interval size: only possible on an index that violates the k-ordering contract */
 
+/* Compact per-read result (sbwt_map_batch_device_compact / sbwt_map_batch_compact): everything start_sbwt_match
+ * yields for a read in 16 bytes, the unique hit included, so that a read costs one quarter of a 64-byte write and
+ * 16 bytes of the host link instead of 48.
+ *   w0 = sa_lo | (sa_hi - sa_lo) << 40
+ *   w1 = payload (40 bits) | aux (16 bits) << 40 | meta (8 bits) << 56
+ * meta & SBWT_CR_UNIQUE: NH = 1, payload = pos0, aux = chr_id, SBWT_CR_RC = is_rc.
+ * meta & SBWT_CR_MULTI: payload = index of the read's first hit in hits[] (which holds ONLY the lists of multi-hit
+ *   reads here), aux = NH (number of hits that survived the filters; the list is in upstream emission order).
+ * neither: NH = 0.  SBWT_CR_SUPPRESSED / _TRUNCATED = SBWT_RF_*; SBWT_CR_INVALID: length < 12 or beyond the record.
+ * meta & SBWT_CR_WIDE: the result does not fit (interval of 2^24 rows or more, chr_id above 65,535, a multi-hit
+ *   read with more than 65,535 raw rows, a position of 2^40 or more): payload = index into wide[], which holds the
+ *   plain record and hit (r.first_hit indexes hits[] as above).
+ * meta & SBWT_CR_NO_SA (only with SBWT_MAP_HITS_ONLY): w0 is 0, the SA interval was not computed. */
+typedef struct sbwt_compact_result {
+  uint64_t w0, w1;
+} sbwt_compact_result;
+#define SBWT_CR_UNIQUE 0x01u
+#define SBWT_CR_RC 0x02u
+#define SBWT_CR_MULTI 0x04u
+#define SBWT_CR_SUPPRESSED 0x08u
+#define SBWT_CR_TRUNCATED 0x10u
+#define SBWT_CR_INVALID 0x20u
+#define SBWT_CR_WIDE 0x40u
+#define SBWT_CR_NO_SA 0x80u
+typedef struct sbwt_wide_result {
+  sbwt_read_result r;
+  sbwt_hit hit; /* the unique hit when r.nh == 1 and the read is not a multi-hit one */
+} sbwt_wide_result;
+/* mode bits of the compact entry points */
+#define SBWT_MAP_HITS_ONLY 1u /* only the hits are wanted (what the SAM output needs): a read whose located search
+                                 prefix and the 32 bases of text stored with it settle the outcome (the one hit, or a
+                                 dead interval) is reported without its SA interval (SBWT_CR_NO_SA) and without the
+                                 access that would fetch it.  Hits, NH and flags are unchanged. */
+
 typedef struct sbwt_index_info {
   uint64_t n;              /* number of suffixes = 2 * real_size + 1 */
   uint64_t real_size;      /* Aligner_table::_realSize = sum of chrLen */
@@ -149,6 +183,28 @@ int sbwt_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t n_reads,
 int sbwt_map_batch_device(sbwt_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_lens, uint64_t n_reads,
                           uint32_t words_per_read, int limit, int strand, sbwt_read_result *d_results,
                           sbwt_hit *d_hits, uint64_t hits_cap, uint64_t *n_hits_host);
+
+/* sbwt_map_batch_device with the compact records above: d_out[n_reads], d_hits[hits_cap] for the lists of multi-hit
+ * reads only (hits_cap may be 0 when there are none), d_wide[wide_cap] for results that do not fit a record (rare;
+ * 1,024 slots are plenty outside adversarial inputs).  counts_host (host pointer, may be NULL) receives
+ * {hit slots in use, wide slots in use}; on SBWT_ERR_CAPACITY they are what a retry needs.  Same search, locate
+ * and filters as sbwt_map_batch_device (start_sbwt_match, searcher.hpp:386-539); `mode`: SBWT_MAP_* bits. */
+int sbwt_map_batch_device_compact(sbwt_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_lens, uint64_t n_reads,
+                                  uint32_t words_per_read, int limit, int strand, uint32_t mode,
+                                  sbwt_compact_result *d_out, sbwt_hit *d_hits, uint64_t hits_cap,
+                                  sbwt_wide_result *d_wide, uint64_t wide_cap, uint64_t counts_host[2]);
+/* Same with HOST buffers (20 bytes in and 16 bytes out per read across the link). */
+int sbwt_map_batch_compact(sbwt_ctx *ctx, const uint32_t *packed, const uint32_t *lens, uint64_t n_reads,
+                           uint32_t words_per_read, int limit, int strand, uint32_t mode, sbwt_compact_result *out,
+                           sbwt_hit *hits, uint64_t hits_cap, sbwt_wide_result *wide, uint64_t wide_cap,
+                           uint64_t counts[2]);
+/* Host helper: compact records (+ wide[], + the lists in list_hits[]) -> the plain layout of sbwt_map_batch:
+ * results[n_reads], hits[] with the unique hit of read r at hits[r] and the lists behind the first n_reads slots in
+ * the order of list_hits (hits must hold n_reads + n_list_hits entries).  Reads flagged SBWT_CR_NO_SA get sa_lo =
+ * sa_hi = 0. */
+int sbwt_compact_expand(const sbwt_compact_result *compact, uint64_t n_reads, const sbwt_wide_result *wide,
+                        uint64_t n_wide, const sbwt_hit *list_hits, uint64_t n_list_hits, sbwt_read_result *results,
+                        sbwt_hit *hits);
 
 /* sbwt_map_batch_device for callers that cannot allocate.  No counterpart upstream (its per-read vectors live on
  * the host heap, searcher.hpp:419-422); it exists for callers that must not reach hipMalloc: code under HIP graph

@@ -44,6 +44,11 @@ class HostTables(C.Structure):
 HIT_DTYPE = np.dtype([("pos0", "<u8"), ("chr_id", "<u4"), ("is_rc", "<u4")])
 RESULT_DTYPE = np.dtype([("sa_lo", "<u8"), ("sa_hi", "<u8"), ("first_hit", "<u8"), ("nh", "<i4"), ("flags", "<u4")])
 
+COMPACT_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8")])
+WIDE_DTYPE = np.dtype([("r", RESULT_DTYPE), ("hit", HIT_DTYPE)])
+MAP_HITS_ONLY = 1
+CR_UNIQUE, CR_RC, CR_MULTI, CR_SUPPRESSED, CR_TRUNCATED, CR_INVALID, CR_WIDE, CR_NO_SA = 1, 2, 4, 8, 16, 32, 64, 128
+
 _lib = None
 
 
@@ -106,6 +111,9 @@ def lib():
     L.sbwt_pack_reads.argtypes = [vp, vp, u64, u32, vp, vp, p(u64)]
     L.sbwt_map_batch_device.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_map_batch.argtypes = [vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
+    L.sbwt_map_batch_device_compact.argtypes = [vp, vp, vp, u64, u32, i32, i32, u32, vp, vp, u64, vp, u64, p(u64 * 2)]
+    L.sbwt_map_batch_compact.argtypes = [vp, vp, vp, u64, u32, i32, i32, u32, vp, vp, u64, vp, u64, p(u64 * 2)]
+    L.sbwt_compact_expand.argtypes = [vp, u64, vp, u64, vp, u64, vp, vp]
     L.sbwt_map_batch_device_static.argtypes = [vp, vp, vp, vp, u64, u32, i32, i32, vp, vp, u64, p(u64)]
     L.sbwt_host_alloc.argtypes = [u64, p(vp)]
     L.sbwt_host_free.argtypes = [vp]
@@ -199,6 +207,20 @@ def build_index_device(d_fwd_packed, g, chr_start, npos_key, npos_val, interval=
                                          nk.ctypes.data, nv.ctypes.data, C.byref(h) if want_index else None,
                                          C.byref(t) if want_tables else None))
     return (Index(h) if want_index else None), (t if want_tables else None)
+
+
+def compact_expand(rec, list_hits, wide):
+    """sbwt_compact_expand: compact records -> (results, hits) in the plain layout of Context.map_batch"""
+    rec = np.ascontiguousarray(rec, dtype=COMPACT_DTYPE)
+    list_hits = np.ascontiguousarray(list_hits, dtype=HIT_DTYPE)
+    wide = np.ascontiguousarray(wide, dtype=WIDE_DTYPE)
+    n = rec.size
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    hits = np.zeros(n + list_hits.size, dtype=HIT_DTYPE)
+    _check(lib().sbwt_compact_expand(rec.ctypes.data, n, wide.ctypes.data if wide.size else None, wide.size,
+                                     list_hits.ctypes.data if list_hits.size else None, list_hits.size, res.ctypes.data,
+                                     hits.ctypes.data))
+    return res, hits
 
 
 def host_tables_free(t):
@@ -317,6 +339,42 @@ class Context:
                 continue
             _check(rc)
             return res, hits[: nh.value]
+
+    def map_batch_compact(self, packed, lens, limit=1000, strand=2, mode=0, hits_cap=None, wide_cap=1024, out=None):
+        """sbwt_map_batch_compact (host buffers) -> (compact records, hits of the multi-hit lists, wide records).
+        out = (compact, hits, wide) arrays to fill (e.g. views of a PinnedBuffer)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = lens.size
+        wpr = packed.shape[1] if packed.ndim == 2 else packed.size // max(n, 1)
+        cap = int(hits_cap if hits_cap is not None else 1024)
+        wcap = int(wide_cap)
+        while True:
+            if out is not None:
+                rec, hits, wide = out
+                cap, wcap = hits.size, wide.size
+            else:
+                rec = np.zeros(n, dtype=COMPACT_DTYPE)
+                hits = np.zeros(max(cap, 1), dtype=HIT_DTYPE)
+                wide = np.zeros(max(wcap, 1), dtype=WIDE_DTYPE)
+            cnt = (C.c_uint64 * 2)()
+            rc = lib().sbwt_map_batch_compact(self._h, packed.ctypes.data, lens.ctypes.data, n, wpr, limit, strand, mode,
+                                              rec.ctypes.data, hits.ctypes.data, cap, wide.ctypes.data, wcap, C.byref(cnt))
+            if rc == -7 and out is None and (hits_cap is None or cnt[1] > wcap):
+                if hits_cap is None:
+                    cap = max(cap, int(cnt[0]) + 16)
+                wcap = max(wcap, int(cnt[1]) + 16)
+                continue
+            _check(rc)
+            return rec[:n], hits[: cnt[0]], wide[: cnt[1]]
+
+    def map_batch_device_compact(self, d_packed, d_lens, n_reads, wpr, d_out, d_hits, hits_cap, d_wide, wide_cap,
+                                 limit=1000, strand=2, mode=0):
+        """Device-pointer compact entry point -> (hit slots in use, wide slots in use)."""
+        cnt = (C.c_uint64 * 2)()
+        _check(lib().sbwt_map_batch_device_compact(self._h, d_packed, d_lens, n_reads, wpr, limit, strand, mode, d_out,
+                                                   d_hits, hits_cap, d_wide, wide_cap, C.byref(cnt)))
+        return int(cnt[0]), int(cnt[1])
 
     def map_batch_device(self, d_packed, d_lens, n_reads, wpr, d_results, d_hits, hits_cap, limit=1000, strand=2):
         """Device-pointer entry point (integers are raw device addresses)."""

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, 
 // One thread per row: the K-mer in front of the row's text position, the upstream steps for that K-mer (exactly as
 // k_kmer_table runs them), and an entry only when they end on this very row, alone.
 __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets,
-                                                    uint32_t tag_bits, unsigned long long* __restrict__ counts) {
+                                                    uint32_t tag_bits, uint32_t with_text, unsigned long long* __restrict__ counts) {
   const uint64_t i = global_thread();
   uint32_t outcome = 0;  // 1 stored, 2 left out
   const uint64_t e = i < ix.n ? ix.sa_full[i] : kNoPosition;
@@ -577,10 +577,22 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
       const uint64_t b = __umul64hi(vv << (64 - 2 * K), n_buckets);
       const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
       const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | (vv & ((1ull << tag_bits) - 1ull));
-      unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + b * kHashSlots;
+      const uint32_t stride = with_text ? 2u : 1u;  // words per slot
+      unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + b * kHashSlots * stride;
       outcome = 2;  // bucket full: this K-mer stays with the fallback path
       for (uint32_t s = 0; s < kHashSlots; ++s)
-        if (atomicCAS(&bk[s], ~0ull, (unsigned long long)slot) == ~0ull) { outcome = 1; break; }
+        if (atomicCAS(&bk[s * stride], ~0ull, (unsigned long long)slot) == ~0ull) {
+          outcome = 1;
+          if (with_text) {
+            // what the read's bases K .. K+31 are compared with: textrc[m - p ..) (search_machine.h, S_CMP: x0 = n - 1 - p)
+            const uint64_t x1 = m - p;
+            const uint32_t* ty = ix.textrc + (x1 >> 4);
+            const uint32_t sh1 = 2u * (uint32_t)(x1 & 15);
+            const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
+            bk[s * stride + 1] = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
+          }
+          break;
+        }
     }
   }
   // statistics: one pair of atomics per wave
@@ -750,20 +762,30 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     }
     uint64_t n_buckets = 0;
     uint32_t tag_bits = 0;
+    bool with_text = false;
+    uint64_t slot_bytes = 8;
     if (H) {
       n_buckets = (raw.n * 8 / 5 + kHashSlots - 1) / kHashSlots;  // 1.6 slots per suffix
       // a tag of at most 16 bits must tell the values of one bucket apart: 2^(tag_bits - 1) >= 4^H / n_buckets
       if (2 * H > 15 && n_buckets < (1ull << (2 * H - 15))) n_buckets = 1ull << (2 * H - 15);
       tag_bits = 1;
       while ((n_buckets << (tag_bits - 1)) < (1ull << (2 * H))) ++tag_bits;
-      const uint64_t direct16 = raw.n >= (1ull << 28) ? (8ull << 32) : 0;  // what an order-16 direct table takes
-      if (n_buckets * (8 * kHashSlots) + direct16 + kKmerHeadroom > (uint64_t)free_b) H = 0;
+      const bool big = raw.n >= (1ull << 28);
+      const uint64_t direct16 = big ? (8ull << 32) : 0;  // what an order-16 direct table takes (34 GB), an order-15 one (9 GB)
+      const uint64_t direct15 = big ? (8ull << 30) : 0;
+      const uint64_t hash8 = n_buckets * (8 * kHashSlots), hash16 = n_buckets * (16 * kHashSlots);
+      // 16-byte slots (with the 32 bases of text behind the prefix) when they fit next to an order-15 direct table,
+      // else 8-byte slots next to an order-16 one, else no hash table; SBWT_HASH_TEXT=0/1 overrides the first choice
+      with_text = hash16 + direct15 + kKmerHeadroom <= (uint64_t)free_b;
+      if (const char* e = getenv("SBWT_HASH_TEXT")) with_text = atoi(e) != 0 && hash16 + kKmerHeadroom <= (uint64_t)free_b;
+      if (!with_text && hash8 + direct16 + kKmerHeadroom > (uint64_t)free_b) H = 0;
+      slot_bytes = with_text ? 16 : 8;
       if (raw.n + 256 >= kPosMask) H = 0;  // the high word of a slot must never be all ones (that marks an empty slot)
     }
     const uint32_t max_direct = H ? 16u : kMaxKmerOrder;
     for (uint32_t k = kKmer + 1; k <= max_direct; ++k) {
       const uint64_t entries = 1ull << (2 * k);
-      const uint64_t other = H ? n_buckets * (8 * kHashSlots) : 0;
+      const uint64_t other = H ? n_buckets * (slot_bytes * kHashSlots) : 0;
       if (entries > 16 * raw.n || entries * 8 + other + kKmerHeadroom > (uint64_t)free_b) break;
       K = k;
     }
@@ -774,15 +796,16 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     if (getenv("SBWT_DEBUG"))
       fprintf(stderr, "[sbwt debug] device memory: %.1f GB free of %.1f GB before the prefix tables; direct order %u (%.1f GB), hash order %u (%.1f GB, %u tag bits)\n",
               free_b / 1e9, total_b / 1e9, K, K > (uint32_t)kKmer ? 8.0 * (double)(1ull << (2 * K)) / 1e9 : 0.0, H,
-              (double)n_buckets * (8 * kHashSlots) / 1e9, tag_bits);
+              (double)n_buckets * (slot_bytes * kHashSlots) / 1e9, tag_bits);
     d.hash_tab = nullptr;
     d.hash_order = 0;
     d.hash_buckets = 0;
     d.hash_tag_bits = 0;
+    d.hash_text = 0;
     // both prefix tables are optional: an allocation that fails (fragmented or shared device memory) leaves the
     // index without that table, slower and with the same results
     uint64_t* htab = nullptr;
-    if (H && (fail_hash || dev_alloc(ix, &htab, n_buckets * kHashSlots))) {
+    if (H && (fail_hash || dev_alloc(ix, &htab, n_buckets * kHashSlots * (slot_bytes / 8)))) {
       (void)hipGetLastError();
       H = 0;
     }
@@ -790,8 +813,8 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       DevTemp<unsigned long long> d_counts;
       SBWT_HIP(d_counts.alloc(2));
       SBWT_HIP(hipMemset(d_counts, 0, 16));
-      SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (8 * kHashSlots)));
-      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, d_counts);
+      SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (slot_bytes * kHashSlots)));
+      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, d_counts);
       SBWT_LAUNCHED();
       unsigned long long h_counts[2];
       SBWT_HIP(hipMemcpy(h_counts, d_counts, 16, hipMemcpyDeviceToHost));
@@ -801,6 +824,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       d.hash_order = H;
       d.hash_buckets = n_buckets;
       d.hash_tag_bits = tag_bits;
+      d.hash_text = with_text ? 1u : 0u;
     }
     d.kmer_order = K;
     d.kmer_tab = nullptr;

@@ -64,6 +64,9 @@ constexpr uint64_t kKmerLocated = 1ull << 63;
 constexpr uint64_t kKmerRunMax = (1ull << 23) - 1;
 // hash_tab: located search prefixes of a LONGER order than a direct table can hold (default 20 bases).  Buckets of
 // four 8-byte slots (32 B: two 16-byte loads; the search kernel is bound by load requests as much as by lines); a slot = text position << 24 | run (saturating) << tag_bits | tag, all ones = empty.
+// With hash_text the slots are 16 bytes (a bucket = 64 B, four loads): the second word holds the 32 bases of text
+// behind the prefix, so that a read of up to hash_order + 32 bases is settled by the bucket alone when only its hits
+// are wanted (SBWT_MAP_HITS_ONLY): equal -> the one hit, different -> the interval dies; no further access.
 // A K-mer v (complemented read codes, as for kmer_tab) is mixed by an odd multiplier modulo 4^K (a bijection), the
 // bucket is the mixed value scaled to the bucket count (so the values of one bucket form an interval shorter than
 // 2^(tag_bits - 1)) and the tag its low tag_bits bits: bucket and tag identify v exactly.  Only K-mers whose
@@ -100,6 +103,7 @@ struct DeviceIndex {
   // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised; kKmerLocated form below)
   const uint64_t* kmer_tab; uint32_t kmer_order;  // kmer_order = 12: no table
   const uint64_t* hash_tab; uint64_t hash_buckets; uint32_t hash_order; uint32_t hash_tag_bits;  // hash_order = 0: none
+  uint32_t hash_text;       // 1: 16-byte slots, the second word = the 32 bases textrc[n-1-pos .. n-1-pos+32) a read's next bases must equal
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;

@@ -35,6 +35,7 @@ struct Counters {
   unsigned long long index_accesses;  // random index accesses k_search_sm issued (one per 128-byte line it needs)
   unsigned long long dfs_count;       // multi-hit reads k_multi_sort handed on to the depth-first kernel
   unsigned long long hash_stats[2];   // hash_tab lookups of k_search_sm, and those that found their prefix
+  unsigned long long wide_count;      // compact output: results that went to wide[]
 };
 
 struct MapArgs {
@@ -44,7 +45,7 @@ struct MapArgs {
   uint32_t wpr;    // 32-bit words per read record (multiple of 4)
   int strand;
   uint64_t limit;  // (uint64_t)(int64_t)limitNumber: the upstream comparison is unsigned (searcher.hpp:415)
-  sbwt_read_result* results;
+  ResultIO io;
   sbwt_hit* hits;
   uint64_t hits_cap;
   Counters* ctr;
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
   Frame* stack = stacks + (uint64_t)lane_global * ix.interval;  // frames 1 .. interval-1
   for (uint64_t q = lane_global; q < qn; q += lanes_total) {
     const uint32_t r = queue[q];
-    sbwt_read_result res = a.results[r];
-    const uint64_t lo = res.sa_lo, hi = res.sa_hi;
+    const MultiRead res = rio_load(a.io, r);
+    const uint64_t lo = res.lo, hi = res.hi;
     MultiState S;
     S.ix = &ix;
     S.out = a.hits + res.first_hit;
@@ -135,9 +136,7 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
         stack[d].pf = nf; stack[d].pe = ne; stack[d].next_c = 0;
       }
     }
-    res.nh = (int32_t)(S.nres < S.cap ? S.nres : S.cap);
-    if (S.truncated) res.flags |= SBWT_RF_TRUNCATED;
-    a.results[r] = res;
+    rio_store_multi(a.io, r, res.first_hit, true, (int32_t)(S.nres < S.cap ? S.nres : S.cap), S.truncated ? SBWT_RF_TRUNCATED : 0u);
   }
 }
 
@@ -188,7 +187,8 @@ struct sbwt_ctx : MapWork {
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
   sbwt_hit* d_hits = nullptr;
-  uint64_t staged_words = 0, staged_reads = 0, staged_hits = 0;
+  sbwt_wide_result* d_wide = nullptr;
+  uint64_t staged_words = 0, staged_reads = 0, staged_hits = 0, staged_wide = 0;
 };
 
 // Launch shapes of the kernels for this index on its device: resident workgroups per kernel variant and the LDS
@@ -262,7 +262,7 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_dfs_queue);
   hipFree(c->d_wave_info);
   hipFree(c->d_stacks);
-  hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits);
+  hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits); hipFree(c->d_wide);
   for (int k = 0; k < 3; ++k)
     if (c->ev[k]) hipEventDestroy(c->ev[k]);
   for (int k = 0; k < 2; ++k)
@@ -307,14 +307,15 @@ __global__ __launch_bounds__(256) void k_bias_first_hit(sbwt_read_result* __rest
 // (multi_base = n_reads for a whole batch); *multi_used = slots the lists took.  Synchronises the stream of `w`.
 // ms (3 floats) / stats (4 counters) may be null; with `accumulate` they are added to.
 static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
-                    uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
-                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate, float* ms_out,
-                    uint64_t* stats_out);
+                    uint32_t words_per_read, int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits,
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate,
+                    float* ms_out, uint64_t* stats_out);
 static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                     uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
                     uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate) {
-  return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, d_results, d_hits, hits_cap, multi_base,
-                  multi_used, accumulate, c->last_ms, c->last_stats);
+  const ResultIO io{d_results, nullptr, nullptr, 0};
+  return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, 0u, d_hits, hits_cap, multi_base,
+                  multi_used, nullptr, accumulate, c->last_ms, c->last_stats);
 }
 
 extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
@@ -350,9 +351,9 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
 }
 
 static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
-                    uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
-                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate, float* ms_out,
-                    uint64_t* stats_out) {
+                    uint32_t words_per_read, int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits,
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate,
+                    float* ms_out, uint64_t* stats_out) {
   MapArgs a;
   a.packed = d_packed;
   a.lens = d_lens;
@@ -360,7 +361,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
   a.wpr = words_per_read;
   a.strand = strand;
   a.limit = (uint64_t)(int64_t)limit;
-  a.results = d_results;
+  a.io = io;
   a.hits = d_hits;
   a.hits_cap = hits_cap;
   a.ctr = w.d_ctr;
@@ -379,7 +380,12 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     sa.wpr = words_per_read;
     sa.strand = strand;
     sa.limit = a.limit;
-    sa.results = d_results;
+    sa.results = io.results;
+    sa.compact = io.compact;
+    sa.wide = io.wide;
+    sa.wide_cap = io.wide_cap;
+    sa.wide_count = &w.d_ctr->wide_count;
+    sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
     sa.hits = d_hits;
     sa.hits_cap = hits_cap;
     sa.multi_queue = w.d_queue;
@@ -410,7 +416,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     MultiSortArgs ms;
     ms.lens = d_lens;
     ms.strand = strand;
-    ms.results = d_results;
+    ms.io = io;
     ms.hits = d_hits;
     ms.multi_base = multi_base;
     ms.queue = w.d_queue;
@@ -449,6 +455,14 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     stats_out[5] = (accumulate ? stats_out[5] : 0) + w.h_ctr->hash_stats[1];
   }
   *multi_used = w.h_ctr->hit_count;
+  if (wide_used) *wide_used = w.h_ctr->wide_count;
+  if (io.compact && w.h_ctr->wide_count > io.wide_cap) {
+    char msg[200];
+    snprintf(msg, sizeof msg, "wide[] too small: %llu results do not fit a 16-byte record, room for %llu",
+             (unsigned long long)w.h_ctr->wide_count, (unsigned long long)io.wide_cap);
+    set_error(msg);
+    return SBWT_ERR_CAPACITY;
+  }
   if (w.h_ctr->overflow) {
     char msg[160];
     snprintf(msg, sizeof msg, "hits buffer too small: %llu slots needed, %llu provided",
@@ -457,6 +471,33 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     return SBWT_ERR_CAPACITY;
   }
   return SBWT_OK;
+}
+
+extern "C" int sbwt_map_batch_device_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                                             uint32_t words_per_read, int limit, int strand, uint32_t mode,
+                                             sbwt_compact_result* d_out, sbwt_hit* d_hits, uint64_t hits_cap,
+                                             sbwt_wide_result* d_wide, uint64_t wide_cap, uint64_t counts_host[2]) {
+  if (!c || (n_reads && (!d_packed || !d_lens || !d_out)) || (hits_cap && !d_hits) || (wide_cap && !d_wide)) {
+    set_error("sbwt_map_batch_device_compact: null pointer");
+    return SBWT_ERR_ARG;
+  }
+  if (n_reads > c->max_reads || words_per_read == 0 || (words_per_read & 3u) || (mode & ~SBWT_MAP_HITS_ONLY)) {
+    set_error("sbwt_map_batch_device_compact: n_reads exceeds the ctx capacity, words_per_read is not a multiple of 4, or unknown mode bits");
+    return SBWT_ERR_ARG;
+  }
+  if (counts_host) counts_host[0] = counts_host[1] = 0;
+  if (n_reads == 0) return SBWT_OK;
+  SBWT_HIP(hipSetDevice(c->ix->device));
+  const ResultIO io{nullptr, d_out, d_wide, wide_cap};
+  uint64_t multi_used = 0, wide_used = 0;
+  const int rc = map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, 0,
+                          &multi_used, &wide_used, false, c->last_ms, c->last_stats);
+  c->last_stats[2] = multi_used;
+  if (counts_host) {  // on SBWT_ERR_CAPACITY: what a retry needs
+    counts_host[0] = multi_used;
+    counts_host[1] = wide_used;
+  }
+  return rc;
 }
 
 extern "C" int sbwt_host_alloc(uint64_t bytes, void** out) {
@@ -702,8 +743,139 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
   const uint64_t lanes = kStaticStackBytes / (ix->d.interval * sizeof(Frame)) / 256 * 256;  // >= 256: interval <= 1024
   w.multi_lanes = (uint32_t)std::min<uint64_t>(lanes, (n_reads + 255) / 256 * 256);
   uint64_t multi_used = 0;
-  const int rc = map_pass(ix, w, d_packed, d_lens, n_reads, words_per_read, limit, strand, d_results, d_hits, hits_cap, n_reads,
-                          &multi_used, false, nullptr, nullptr);
+  const ResultIO io{d_results, nullptr, nullptr, 0};
+  const int rc = map_pass(ix, w, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, 0u, d_hits, hits_cap, n_reads,
+                          &multi_used, nullptr, false, nullptr, nullptr);
   if (n_hits_host) *n_hits_host = n_reads + multi_used;  // on SBWT_ERR_CAPACITY: what a retry needs
   return rc;
+}
+
+// ---- compact records through host buffers ---------------------------------------------------------------------
+// payload of every record of a sub-batch that points into wide[] += bias (the sub-batch numbered its slots from 0)
+__global__ __launch_bounds__(256) void k_bias_wide(sbwt_compact_result* __restrict__ out, uint64_t n, uint64_t bias) {
+  const uint64_t r = global_thread();
+  if (r >= n) return;
+  const uint64_t w1 = out[r].w1;
+  if ((uint32_t)(w1 >> 56) & SBWT_CR_WIDE) out[r].w1 = (w1 & ~kPosMask) | (((w1 & kPosMask) + bias) & kPosMask);
+}
+
+extern "C" int sbwt_map_batch_compact(sbwt_ctx* c, const uint32_t* packed, const uint32_t* lens, uint64_t n_reads,
+                                      uint32_t words_per_read, int limit, int strand, uint32_t mode, sbwt_compact_result* out,
+                                      sbwt_hit* hits, uint64_t hits_cap, sbwt_wide_result* wide, uint64_t wide_cap,
+                                      uint64_t counts[2]) {
+  if (!c || (n_reads && (!packed || !lens || !out)) || (hits_cap && !hits) || (wide_cap && !wide)) {
+    set_error("sbwt_map_batch_compact: null pointer");
+    return SBWT_ERR_ARG;
+  }
+  if (n_reads > c->max_reads || words_per_read == 0 || (words_per_read & 3u) || (mode & ~SBWT_MAP_HITS_ONLY)) {
+    set_error("sbwt_map_batch_compact: n_reads exceeds the ctx capacity, words_per_read is not a multiple of 4, or unknown mode bits");
+    return SBWT_ERR_ARG;
+  }
+  if (counts) counts[0] = counts[1] = 0;
+  if (n_reads == 0) return SBWT_OK;
+  SBWT_HIP(hipSetDevice(c->ix->device));
+  // staging: the 32-byte result staging of the plain entry point holds two compact records per slot
+  const uint64_t words = n_reads * words_per_read;
+  uint64_t lens_have = c->staged_reads, res_have = c->staged_reads;
+  if (int rc = ensure(&c->d_packed, &c->staged_words, words)) return rc;
+  if (int rc = ensure(&c->d_lens, &lens_have, n_reads)) return rc;
+  if (int rc = ensure(&c->d_results, &res_have, n_reads)) return rc;
+  c->staged_reads = lens_have < res_have ? lens_have : res_have;
+  if (int rc = ensure(&c->d_hits, &c->staged_hits, hits_cap ? hits_cap : 1)) return rc;
+  if (int rc = ensure(&c->d_wide, &c->staged_wide, wide_cap ? wide_cap : 1)) return rc;
+  sbwt_compact_result* d_out = reinterpret_cast<sbwt_compact_result*>(c->d_results);
+  uint64_t sub = 2u << 20;
+  if (const char* e = getenv("SBWT_SUBBATCH")) sub = strtoull(e, nullptr, 10);
+  sub = (sub + 63) & ~63ull;
+  if (!sub || n_reads < 2 * sub || !c->s_in || !c->s_out) sub = n_reads;  // one piece
+  uint64_t used_multi = 0, used_wide = 0;
+  int rc = SBWT_OK;
+  hipError_t he = hipSuccess;
+  auto copy_in = [&](uint64_t a0, uint64_t n0, int slot) -> hipError_t {
+    hipError_t e = hipMemcpyAsync(c->d_packed + a0 * words_per_read, packed + a0 * words_per_read, n0 * words_per_read * 4,
+                                  hipMemcpyHostToDevice, c->s_in);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_lens + a0, lens + a0, n0 * 4, hipMemcpyHostToDevice, c->s_in);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_in[slot], c->s_in);
+    return e;
+  };
+  he = copy_in(0, std::min(sub, n_reads), 0);
+  int slot = 0;
+  for (uint64_t a0 = 0; a0 < n_reads && he == hipSuccess; a0 += sub, slot ^= 1) {
+    const uint64_t n0 = std::min(sub, n_reads - a0);
+    if (a0 + sub < n_reads) he = copy_in(a0 + sub, std::min(sub, n_reads - a0 - sub), slot ^ 1);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, c->ev_in[slot], 0);
+    if (he != hipSuccess) break;
+    // the lists of this piece go behind those of the pieces before it; its wide slots likewise
+    const ResultIO io{nullptr, d_out + a0, c->d_wide + std::min(used_wide, wide_cap), wide_cap - std::min(used_wide, wide_cap)};
+    uint64_t mu = 0, wu = 0;
+    const int prc = map_pass(c->ix, *c, c->d_packed + a0 * words_per_read, c->d_lens + a0, n0, words_per_read, limit, strand, io,
+                             mode, c->d_hits, hits_cap, used_multi, &mu, &wu, a0 != 0, c->last_ms, c->last_stats);
+    if (prc != SBWT_OK && prc != SBWT_ERR_CAPACITY) { rc = prc; break; }
+    if (prc == SBWT_ERR_CAPACITY) rc = prc;  // keep counting: the caller learns what the whole batch needs
+    if (rc == SBWT_OK) {
+      if (wu && used_wide) {
+        k_bias_wide<<<grid_items(n0, 256), 256, 0, c->stream>>>(d_out + a0, n0, used_wide);
+        he = hipGetLastError();
+      }
+      if (he == hipSuccess) he = hipEventRecord(c->ev_k, c->stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(c->s_out, c->ev_k, 0);
+      if (he == hipSuccess) he = hipMemcpyAsync(out + a0, d_out + a0, n0 * sizeof(sbwt_compact_result), hipMemcpyDeviceToHost, c->s_out);
+      if (he == hipSuccess && mu)
+        he = hipMemcpyAsync(hits + used_multi, c->d_hits + used_multi, mu * sizeof(sbwt_hit), hipMemcpyDeviceToHost, c->s_out);
+      if (he == hipSuccess && wu)
+        he = hipMemcpyAsync(wide + used_wide, c->d_wide + used_wide, wu * sizeof(sbwt_wide_result), hipMemcpyDeviceToHost, c->s_out);
+    }
+    used_multi += mu;
+    used_wide += wu;
+  }
+  const hipError_t e1 = hipStreamSynchronize(c->s_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->s_out);
+  if (he == hipSuccess) he = e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3);
+  if (he != hipSuccess) return hip_fail(he, "sbwt_map_batch_compact", __FILE__, __LINE__);
+  c->last_stats[2] = used_multi;
+  if (counts) { counts[0] = used_multi; counts[1] = used_wide; }
+  return rc;
+}
+
+extern "C" int sbwt_compact_expand(const sbwt_compact_result* compact, uint64_t n_reads, const sbwt_wide_result* wide,
+                                   uint64_t n_wide, const sbwt_hit* list_hits, uint64_t n_list_hits, sbwt_read_result* results,
+                                   sbwt_hit* hits) {
+  if ((n_reads && (!compact || !results || !hits)) || (n_wide && !wide) || (n_list_hits && !list_hits)) {
+    set_error("sbwt_compact_expand: null pointer");
+    return SBWT_ERR_ARG;
+  }
+  for (uint64_t k = 0; k < n_list_hits; ++k) hits[n_reads + k] = list_hits[k];
+  for (uint64_t r = 0; r < n_reads; ++r) {
+    const uint64_t w0 = compact[r].w0, w1 = compact[r].w1;
+    const uint32_t meta = (uint32_t)(w1 >> 56);
+    const uint64_t payload = w1 & kPosMask;
+    sbwt_read_result o;
+    if (meta & SBWT_CR_WIDE) {
+      if (payload >= n_wide) {
+        set_error("sbwt_compact_expand: a record points past wide[]");
+        return SBWT_ERR_ARG;
+      }
+      o = wide[payload].r;
+      if (o.nh == 1 && !(meta & SBWT_CR_MULTI)) { hits[r] = wide[payload].hit; o.first_hit = r; }
+      else if (o.nh > 0) o.first_hit += n_reads;
+      else o.first_hit = 0;
+    } else {
+      o.sa_lo = w0 & kPosMask;
+      o.sa_hi = o.sa_lo + (w0 >> kPosBits);
+      o.flags = ((meta >> 3) & 3u) | ((meta & SBWT_CR_INVALID) ? 0x80000000u : 0u);
+      o.nh = 0;
+      o.first_hit = 0;
+      if (meta & SBWT_CR_UNIQUE) {
+        o.nh = 1;
+        o.first_hit = r;
+        hits[r].pos0 = payload;
+        hits[r].chr_id = (uint32_t)(w1 >> kPosBits) & 0xFFFFu;
+        hits[r].is_rc = (meta & SBWT_CR_RC) ? 1u : 0u;
+      } else if (meta & SBWT_CR_MULTI) {
+        o.nh = (int32_t)((w1 >> kPosBits) & 0xFFFFu);
+        o.first_hit = o.nh > 0 ? n_reads + payload : 0;
+      }
+    }
+    results[r] = o;
+  }
+  return SBWT_OK;
 }

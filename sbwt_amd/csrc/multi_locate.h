@@ -25,7 +25,7 @@ constexpr uint32_t kSortMax = 1024;
 struct MultiSortArgs {
   const uint32_t* lens;
   int strand;
-  sbwt_read_result* results;
+  ResultIO io;
   sbwt_hit* hits;
   uint64_t multi_base;                   // first slot of hits[] for multi-hit lists (n_reads, unless the caller splits a batch)
   const uint32_t* queue;                 // wave w of the search kernel queued its reads at queue[w * chunk ..)
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
       bool mine = false;
       if (q0 + tid < wi.count) {
         my_r = a.queue[(uint64_t)w * a.chunk + q0 + tid];
-        const uint64_t m = a.results[my_r].sa_hi - a.results[my_r].sa_lo;
+        const MultiRead mr = rio_load(a.io, my_r);
+        const uint64_t m = mr.hi - mr.lo;
         mine = T == 64 ? m <= kCap : m > kSortMax / 4;
       }
       uint32_t n_list;
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
       team_sync<T>();
       for (uint32_t li = 0; li < n_list; ++li) {
         const uint32_t r = list[li];
-        sbwt_read_result res = a.results[r];
-        const uint64_t lo = res.sa_lo, m = res.sa_hi - res.sa_lo;
+        MultiRead res = rio_load(a.io, r);
+        const uint64_t lo = res.lo, m = res.hi - res.lo;
         const uint32_t L = a.lens[r];
         res.first_hit += a.multi_base + wi.slots;  // wave-relative until now
         if (tid == 0) *s_bad = (m > kCap || no_sort_path) ? 1u : 0u;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
         team_sync<T>();
         if (*s_bad) {
           if (tid == 0) {
-            a.results[r].first_hit = res.first_hit;
+            rio_store_multi(a.io, r, res.first_hit, false, 0, 0u);
             a.dfs_queue[atomicAdd(a.dfs_count, 1ull)] = r;
           }
           team_sync<T>();
@@ -361,10 +362,7 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
             base += (uint32_t)__popcll(bal);
           }
         }
-        if (tid == 0) {
-          a.results[r].first_hit = res.first_hit;
-          a.results[r].nh = (int32_t)base;
-        }
+        if (tid == 0) rio_store_multi(a.io, r, res.first_hit, true, (int32_t)base, 0u);
         team_sync<T>();
       }
     }

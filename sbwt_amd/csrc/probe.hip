@@ -58,7 +58,7 @@ extern "C" int sbwt_probe_random_access(const sbwt_index* ix, uint32_t chains_pe
   }
   SBWT_HIP(hipSetDevice(ix->device));
   const void* table = ix->d.hash_tab ? (const void*)ix->d.hash_tab : (const void*)ix->d.sa_full;
-  const uint64_t bytes = ix->d.hash_tab ? ix->d.hash_buckets * (8ull * kHashSlots) : ix->d.n * 8ull;
+  const uint64_t bytes = ix->d.hash_tab ? ix->d.hash_buckets * ((ix->d.hash_text ? 16ull : 8ull) * kHashSlots) : ix->d.n * 8ull;
   const uint64_t n_lines = bytes / 128;
   if (n_lines < 2) {
     set_error("sbwt_probe_random_access: the index is too small to probe");

@@ -54,6 +54,63 @@ __device__ __forceinline__ void sm_funnel128(uint64_t q0, uint64_t q1, uint64_t 
   c1 = sh ? ((q1 >> sh) | (q2 << (64 - sh))) : q1;
 }
 
+// Where the per-read records live: the 32-byte records, or (compact output) the 16-byte entries with wide[] behind
+// them.  The multi-hit locate kernels read a queued read's interval and reserved slots and write back its list's
+// place and NH through these.
+struct ResultIO {
+  sbwt_read_result* results;
+  sbwt_compact_result* compact;  // null: results[]
+  sbwt_wide_result* wide;
+  uint64_t wide_cap;
+};
+struct MultiRead {
+  uint64_t lo, hi, first_hit;
+};
+__device__ __forceinline__ MultiRead rio_load(const ResultIO& io, uint64_t r) {
+  MultiRead m;
+  if (!io.compact) {
+    const sbwt_read_result res = io.results[r];
+    m.lo = res.sa_lo; m.hi = res.sa_hi; m.first_hit = res.first_hit;
+    return m;
+  }
+  const sbwt_compact_result c = io.compact[r];
+  const uint64_t payload = c.w1 & kPosMask;
+  if ((uint32_t)(c.w1 >> 56) & SBWT_CR_WIDE) {
+    m.lo = m.hi = m.first_hit = 0;  // a slot past wide_cap was never written: the call fails with SBWT_ERR_CAPACITY
+    if (payload < io.wide_cap) {
+      const sbwt_read_result res = io.wide[payload].r;
+      m.lo = res.sa_lo; m.hi = res.sa_hi; m.first_hit = res.first_hit;
+    }
+    return m;
+  }
+  m.lo = c.w0 & kPosMask;
+  m.hi = m.lo + (c.w0 >> kPosBits);
+  m.first_hit = payload;
+  return m;
+}
+// a queued multi-hit read's list starts at hits[first_hit] and holds nh hits; add_flags: SBWT_RF_* to set
+__device__ __forceinline__ void rio_store_multi(const ResultIO& io, uint64_t r, uint64_t first_hit, bool set_nh, int32_t nh,
+                                                uint32_t add_flags) {
+  if (!io.compact) {
+    io.results[r].first_hit = first_hit;
+    if (set_nh) io.results[r].nh = nh;
+    if (add_flags) io.results[r].flags |= add_flags;
+    return;
+  }
+  const uint64_t w1 = io.compact[r].w1;
+  const uint32_t meta = (uint32_t)(w1 >> 56);
+  if (meta & SBWT_CR_WIDE) {
+    const uint64_t slot = w1 & kPosMask;
+    if (slot >= io.wide_cap) return;
+    io.wide[slot].r.first_hit = first_hit;
+    if (set_nh) io.wide[slot].r.nh = nh;
+    if (add_flags) io.wide[slot].r.flags |= add_flags;
+    return;
+  }
+  const uint64_t aux = set_nh ? (uint64_t)(uint32_t)nh & 0xFFFFull : (w1 >> kPosBits) & 0xFFFFull;
+  io.compact[r].w1 = (first_hit & kPosMask) | (aux << kPosBits) | ((uint64_t)(meta | (add_flags << 3)) << 56);
+}
+
 struct WaveInfo {
   uint64_t slots;      // hit slots the wave's multi-hit reads need (k_search_sm) -> exclusive prefix over waves (k_multi_plan)
   uint32_t count;      // multi-hit reads of the wave
@@ -80,6 +137,13 @@ struct SmArgs {
   // what a ring entry holds (kRingWidthMax, 16 bits of chr_id; a test knob lowers them to reach the direct path)
   uint64_t ring_width_max;
   uint32_t ring_chr_max;
+  // compact output (sbwt_map_batch_device_compact): the 16-byte ring entries ARE the per-read records, results /
+  // hits[read index] are not written; a result that does not fit an entry goes to wide[] (slot from wide_count)
+  sbwt_compact_result* compact;  // null: the 32-byte records + hits[read index]
+  sbwt_wide_result* wide;
+  unsigned long long* wide_count;
+  uint64_t wide_cap;
+  uint32_t hits_only;  // SBWT_MAP_HITS_ONLY: the SA interval of a read the located-prefix text settles is not needed
 };
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
@@ -88,7 +152,10 @@ constexpr uint32_t kSmRing = 512;       // results staged per wave (LDS, 16 B ea
 // ring entry: word 0 = sa_lo | (sa_hi - sa_lo) << 40 (24 bits), word 1 = payload (40 bits) | chr_id << 40 (16 bits) |
 // meta << 56.  A result that does not fit (interval of 2^24 rows or more, chr_id above 65535) is written to global
 // memory at once and its entry only says so.
-constexpr uint32_t R_NH = 1u, R_RC = 2u, R_MULTI = 4u, R_FLAGS_SHIFT = 3u /* 2 bits */, R_INVALID = 32u, R_DIRECT = 64u;
+constexpr uint32_t R_NH = 1u, R_RC = 2u, R_MULTI = 4u, R_FLAGS_SHIFT = 3u /* 2 bits */, R_INVALID = 32u, R_DIRECT = 64u, R_NOSA = 128u;
+static_assert(R_NH == SBWT_CR_UNIQUE && R_RC == SBWT_CR_RC && R_MULTI == SBWT_CR_MULTI && (1u << R_FLAGS_SHIFT) == SBWT_CR_SUPPRESSED &&
+              (2u << R_FLAGS_SHIFT) == SBWT_CR_TRUNCATED && R_INVALID == SBWT_CR_INVALID && R_DIRECT == SBWT_CR_WIDE && R_NOSA == SBWT_CR_NO_SA,
+              "a ring entry is a sbwt_compact_result");
 constexpr uint64_t kRingWidthMax = 0xFFFFFFull;
 
 __device__ __forceinline__ void sm_emit(const SmArgs& a, uint64_t rd, uint64_t lo, uint64_t hi, uint64_t payload,
@@ -109,11 +176,35 @@ __device__ __forceinline__ void sm_emit(const SmArgs& a, uint64_t rd, uint64_t l
   }
 }
 
+// compact output, a result no 16-byte entry holds: the whole record goes to wide[]; returns its slot (the entry's
+// payload).  Past wide_cap nothing is written; the host sees the count and reports what a retry needs.
+__device__ __forceinline__ uint64_t sm_emit_wide(const SmArgs& a, uint64_t lo, uint64_t hi, uint64_t payload, uint32_t chr_id,
+                                                 uint32_t meta) {
+  const uint64_t slot = atomicAdd(a.wide_count, 1ull);
+  if (slot < a.wide_cap) {
+    sbwt_wide_result w;
+    w.r.sa_lo = lo;
+    w.r.sa_hi = hi;
+    w.r.first_hit = (meta & R_MULTI) ? payload : 0;
+    w.r.nh = (meta & R_NH) ? 1 : 0;
+    w.r.flags = ((meta >> R_FLAGS_SHIFT) & 3u) | ((meta & R_INVALID) ? kFlagInvalid : 0u);
+    w.hit.pos0 = (meta & R_NH) ? payload : 0;
+    w.hit.chr_id = chr_id;
+    w.hit.is_rc = (meta & R_RC) ? 1u : 0u;
+    a.wide[slot] = w;
+  }
+  return slot;
+}
+
 // one finished read leaves the ring: lane l writes read first + l, so a wave writes 2 KB of results and 1 KB of hits
 // as whole lines
 __device__ __forceinline__ void sm_flush(const SmArgs& a, const uint4* ring, uint64_t range_begin, uint64_t rd, bool valid) {
   if (!valid) return;
   const uint4 e = ring[(size_t)((rd - range_begin) & (kSmRing - 1))];
+  if (a.compact) {  // the entry is the record: a wave writes 1 KB of whole lines
+    reinterpret_cast<uint4*>(a.compact)[rd] = e;
+    return;
+  }
   const uint64_t e0 = ((uint64_t)e.y << 32) | e.x, e1 = ((uint64_t)e.w << 32) | e.z;
   const uint32_t meta = (uint32_t)(e1 >> 56);
   if (meta & R_DIRECT) return;
@@ -132,6 +223,7 @@ constexpr uint32_t A_CUR_KH = 1u << 22;   // ... which came from hash_tab: a loc
 constexpr uint32_t A_CUR_P2 = 1u << 23;   // (long-read variant) w2 holds the 64-base piece after the one in w
 constexpr uint32_t A_REQ_P2 = 1u << 25;   // (long-read variant) ... and is on its way with the next piece
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
+constexpr uint32_t A_SETTLED = 1u << 26;  // (hits only) the text in the hash slot settled the read: hit at p, or dead; no SA interval
 
 // prefetch pipeline of a lane: its next read (1) and the one after (2)
 constexpr uint32_t PF_W1 = 1u, PF_K1 = 2u, PF_W2 = 4u;        // record of 1, prefix entry of 1, record of 2 are here
@@ -193,16 +285,36 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0, mL = 0, pf = 0;
   uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0;
   uint64_t ck = 0;                                     // prefix entry of the read about to start
+  uint64_t ckt = 0, nkt = 0;                           // (hash_text) the 32 bases of text behind the located prefix of r, of rn
   uint64_t nw_lo = 0, nw_hi = 0, nk = 0, mw_lo = 0, mw_hi = 0;  // records of rn (with its prefix entry) and rn2
   uint64_t w2_lo = 0, w2_hi = 0, nw2_lo = 0, nw2_hi = 0;        // kLong: bases 64..127 of the current read and of rn
 
   // interval after the search prefix, from a kmer_tab entry (device_layout.h)
-  auto apply_prefix = [&](uint64_t e, uint32_t Kp) {  // Kp = bases the entry covers (kmer_order, or hash_order)
+  const bool kInline = a.hits_only && ix.hash_text;  // wave-uniform
+  auto apply_prefix = [&](uint64_t e, uint32_t Kp, bool from_hash) {  // Kp = bases the entry covers (kmer_order, or hash_order)
     uint64_t width = e >> kPosBits;
     if (e & kKmerLocated) {
       // one row, already located: straight to the text comparison when it can carry the rest of the read
       const uint64_t pos = e & kPosMask, run = (e >> kPosBits) & kKmerRunMax;
       const uint64_t rem = (uint64_t)L - Kp;
+      if (kInline && from_hash && rem >= 1 && rem <= 32 && run > rem && pos >= rem) {
+        // hits only: the prefix is ONE located row, so the rest of the read either equals the text in front of it
+        // (the one hit, rem positions further down) or the interval dies; the slot carries those 32 bases of text
+        uint64_t r0, r1;
+        sm_funnel128(w_lo, w_hi, 0, 0, Kp, r0, r1);
+        const uint64_t diff = (r0 ^ ckt) & (rem < 32 ? (1ull << (2 * rem)) - 1ull : ~0ull);
+        aux |= A_TRIED | A_SETTLED;
+        if (diff == 0) {
+          p = pos - rem;
+          j = L;
+          lo = 0;
+          hi = 1;
+          aux |= A_LOCATED;
+        } else {
+          lo = hi = 0;
+        }
+        return;
+      }
       if (rem >= 1 && run > rem && pos >= rem) {
         p = pos;
         j = Kp;
@@ -231,6 +343,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       st = S_CMP;
       return false;
     }
+    if (aux & A_SETTLED) return true;
     if (lo >= hi || j >= L) return true;
     if ((j & 63u) == 0 && j >= 64u && !(aux & A_PIECE)) {
       aux |= A_PIECE;  // w must hold the piece j is in before anything looks at the next bases
@@ -281,7 +394,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = hi = 0;
           st = S_FIN;
         } else if (had & A_CUR_K) {
-          apply_prefix(ck, (had & A_CUR_KH) ? ix.hash_order : K);
+          apply_prefix(ck, (had & A_CUR_KH) ? ix.hash_order : K, (had & A_CUR_KH) != 0);
           if (choose()) st = S_FIN;
         } else {
           st = S_KMER;
@@ -460,7 +573,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
         if (H && !(pf & PF_H1) && nL > H) {
           // the hash table first: a located prefix of H bases, or nothing
           const uint64_t vv = hash_mix((~nw_lo) & hmask, H);
-          ph = reinterpret_cast<const uint4*>(ix.hash_tab) + __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) * 2u;
+          ph = reinterpret_cast<const uint4*>(ix.hash_tab) + __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) * (ix.hash_text ? 4u : 2u);
           pf |= PF_RH1;
           tally += 1;
         } else if (ix.kmer_tab && nL >= K) {
@@ -478,7 +591,9 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint64_t vc = *pc, ve = *pe, vk = *pk, vl = *pl;
     const uint32_t vd = *pd;
     uint4 vh0 = make_uint4(0, 0, 0, 0), vh1 = vh0;
+    uint4 vh2 = vh0, vh3 = vh0;
     if (H) { vh0 = ph[0]; vh1 = ph[1]; }  // wave-uniform condition
+    if (H && ix.hash_text) { vh2 = ph[2]; vh3 = ph[3]; }  // 16-byte slots: position word + 32 bases of text
     uint4 vr2 = make_uint4(0, 0, 0, 0);
     if (kLong) vr2 = *pr2;
     __builtin_amdgcn_wave_barrier();
@@ -508,12 +623,14 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       const uint64_t vv = hash_mix((~nw_lo) & hmask, H);
       // (tag in the low word; the high word of an empty slot is all ones, that of a position never is)
       const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u, tag = (uint32_t)vv & tmask;
-      const uint32_t sl_lo[4] = {vh0.x, vh0.z, vh1.x, vh1.z};
-      const uint32_t sl_hi[4] = {vh0.y, vh0.w, vh1.y, vh1.w};
+      const bool wide_slots = ix.hash_text != 0;  // wave-uniform
+      const uint32_t sl_lo[4] = {vh0.x, wide_slots ? vh1.x : vh0.z, wide_slots ? vh2.x : vh1.x, wide_slots ? vh3.x : vh1.z};
+      const uint32_t sl_hi[4] = {vh0.y, wide_slots ? vh1.y : vh0.w, wide_slots ? vh2.y : vh1.y, wide_slots ? vh3.y : vh1.w};
+      const uint64_t sl_tx[4] = {u64_of(vh0.z, vh0.w), u64_of(vh1.z, vh1.w), u64_of(vh2.z, vh2.w), u64_of(vh3.z, vh3.w)};
       uint64_t found = ~0ull;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) found = u64_of(sl_lo[q], sl_hi[q]);
+        if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) { found = u64_of(sl_lo[q], sl_hi[q]); nkt = sl_tx[q]; }
       pf = (pf | PF_H1) & ~PF_RH1;
       tally_h += 0x10000u + (found != ~0ull ? 1u : 0u);
       if (found != ~0ull) {
@@ -545,7 +662,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = vc;
           hi = ve;
         } else {
-          apply_prefix(vc, K);
+          apply_prefix(vc, K, false);
         }
         finish = choose();
         break;
@@ -772,10 +889,25 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       }
       // flags: bits 0..1 and bit 31 are in use
       meta |= ((flags & 3u) << R_FLAGS_SHIFT) | ((flags & kFlagInvalid) ? R_INVALID : 0u);
-      const uint64_t width = hi - lo;
-      if (hi < lo || width >= a.ring_width_max || chr_id > a.ring_chr_max || payload > kPosMask) {
-        sm_emit(a, r, lo, hi, payload, chr_id, meta);  // does not fit a ring entry
-        meta = R_DIRECT;
+      if (aux & A_SETTLED) {  // no SA interval was computed (hits only)
+        meta |= R_NOSA;
+        lo = hi = 0;
+      }
+      uint64_t width = hi - lo;
+      if (hi < lo || width >= a.ring_width_max || chr_id > a.ring_chr_max || payload > kPosMask ||
+          (a.compact && want > 0xFFFFull)) {  // (compact: the entry of a multi-hit read carries NH in 16 bits)
+        // does not fit a ring entry
+        if (a.compact) {
+          payload = sm_emit_wide(a, lo, hi, payload, chr_id, meta);
+          meta |= R_DIRECT;
+          lo = 0;
+          width = 0;
+          chr_id = 0;
+          if (payload > kPosMask) payload = kPosMask;  // (2^40 wide results cannot happen; keeps the entry well-formed)
+        } else {
+          sm_emit(a, r, lo, hi, payload, chr_id, meta);
+          meta = R_DIRECT;
+        }
       }
       const uint64_t e0 = lo | (width << kPosBits), e1 = payload | ((uint64_t)chr_id << kPosBits) | ((uint64_t)meta << 56);
       ring[(size_t)((r - range_begin) & (kSmRing - 1))] =
@@ -796,6 +928,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       w_hi = nw_hi;
       L = nL;
       ck = nk;
+      ckt = nkt;
       nw_lo = mw_lo;
       nw_hi = mw_hi;
       nL = mL;

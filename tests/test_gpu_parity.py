@@ -32,7 +32,39 @@ def assert_same(sb, ctx, oix, reads, limit=1000, strand=2):
         a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
         b = ohits[int(first[r]): int(first[r]) + int(nh[r])]
         assert np.array_equal(a, b), "read %d: hit list differs (order matters)" % r
+    assert_same_compact(sb, ctx, reads, packed, lens, lo, hi, nh, first, ohits, limit, strand)
     return res, hits
+
+
+def assert_same_compact(sb, ctx, reads, packed, lens, lo, hi, nh, first, ohits, limit, strand):
+    """the same batch through the compact records (sbwt_map_batch_compact), with SA intervals and hits-only: every
+    parity test of this suite covers both layouts"""
+    for mode in (0, sb.MAP_HITS_ONLY):
+        rec, lists, wide = ctx.map_batch_compact(packed, lens, limit=limit, strand=strand, mode=mode)
+        meta = (rec["w1"] >> np.uint64(56)).astype(np.uint32)
+        res, hits = sb.compact_expand(rec, lists, wide)
+        np.testing.assert_array_equal(res["nh"], nh)
+        no_sa = (meta & sb.CR_NO_SA) != 0
+        if mode == 0:
+            assert not no_sa.any()
+        else:
+            # settled without an interval: exactly one row (nh 1, or 0 after the filters / when suppressed) or dead
+            assert (nh[no_sa] <= 1).all()
+        keep = ~no_sa
+        np.testing.assert_array_equal(res["sa_lo"][keep], lo[keep])
+        np.testing.assert_array_equal(res["sa_hi"][keep], hi[keep])
+        np.testing.assert_array_equal(res["flags"][keep], ctx_flags(lo[keep], hi[keep], limit))
+        for r in np.nonzero(nh)[0]:
+            a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
+            b = ohits[int(first[r]): int(first[r]) + int(nh[r])]
+            assert np.array_equal(a, b), "compact mode %d, read %d: hit list differs" % (mode, r)
+
+
+def ctx_flags(lo, hi, limit):
+    """SBWT_RF_SUPPRESSED exactly where the raw interval exceeds -m (unsigned compare, searcher.hpp:415)"""
+    width = np.where(hi > lo, hi - lo, 0).astype(np.uint64)
+    lim = np.uint64(limit & 0xFFFFFFFFFFFFFFFF)
+    return (width > lim).astype(np.uint32)
 
 
 @pytest.fixture(scope="module")
