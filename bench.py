@@ -351,6 +351,9 @@ def main():
     ap.add_argument("--genome", choices=["iid", "repeats"], default="iid", help="repeats: 40 %% of the bases in diverged repeat families")
     ap.add_argument("--rank-path", action="store_true", help="no memoised search prefix: backward search through rank queries")
     ap.add_argument("--shuffle-ties", action="store_true", help="suffix order stopped at sort_len 256, ties in arbitrary order")
+    ap.add_argument("--layout", choices=["plain", "compact", "hits"], default="hits",
+                    help="per-read output: plain = 32-byte record + hit slot per read (sbwt_map_batch_device); compact = 16-byte "
+                         "records (sbwt_map_batch_device_compact); hits = compact with SBWT_MAP_HITS_ONLY (what SAM output needs)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -416,29 +419,40 @@ def main():
     torch.cuda.synchronize()
     t_reads = time.time() - t0
 
-    res_bytes = n_reads * 32
-    results = torch.empty(res_bytes, dtype=torch.uint8, device=dev)
     many_hits = args.repeats or args.genome == "repeats"
-    hits_cap = n_reads + (1 << 20) if not many_hits else int(min(80 * n_reads, 6e9))
-    hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
     ctx = sbwt_amd.Context(ix, n_reads)
+    compact = args.layout != "plain"
+    mode = sbwt_amd.MAP_HITS_ONLY if args.layout == "hits" else 0
+    wide_cap = 1 << 16
+    if compact:
+        results = torch.empty(n_reads * 16, dtype=torch.uint8, device=dev)            # sbwt_compact_result[n_reads]
+        hits_cap = (1 << 20) if not many_hits else int(min(80 * n_reads, 6e9))        # lists of multi-hit reads only
+        wide = torch.empty(wide_cap * 48, dtype=torch.uint8, device=dev)
+    else:
+        results = torch.empty(n_reads * 32, dtype=torch.uint8, device=dev)            # sbwt_read_result[n_reads]
+        hits_cap = n_reads + (1 << 20) if not many_hits else int(min(80 * n_reads, 6e9))
+    hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
 
     def step():
-        return ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
-                                    hits.data_ptr(), hits_cap, limit=1000, strand=2)
+        if compact:
+            return ctx.map_batch_device_compact(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
+                                                hits.data_ptr(), hits_cap, wide.data_ptr(), wide_cap, limit=1000, strand=2,
+                                                mode=mode)
+        return (ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
+                                     hits.data_ptr(), hits_cap, limit=1000, strand=2), 0)
 
     from sbwt_amd import shard
     kernel_ms = []
-    last = {"hits": 0}
+    last = {"hits": (0, 0)}
 
     def timed_step():
-        last["hits"] = step()                # synchronises its own stream before returning
-        kernel_ms.append(ctx.last_timing())  # HIP events on the ctx stream, around the kernels of this step
+        last["hits"] = step()                   # synchronises its own stream before returning
+        kernel_ms.append(ctx.last_timing_ex())  # HIP events on the ctx stream, around the kernels of this step
 
     for _ in range(args.warmup):
         step()
     elapsed = shard.timed_steps(timed_step, args.steps, 0, dist=dist, sync=torch.cuda.synchronize, device=dev)
-    n_hits = last["hits"]
+    n_hits, n_wide = last["hits"]
 
     if rank != 0:
         if dist is not None:
@@ -446,16 +460,52 @@ def main():
             dist.destroy_process_group()
         return
 
+    if compact:
+        # decode the compact records on the device into the plain layout (only for the checks below, after the timed region)
+        rec = results.view(torch.int64).view(-1, 2)
+        w0, w1 = rec[:, 0], rec[:, 1]
+        meta = (w1 >> 56) & 0xFF
+        m40 = (1 << 40) - 1
+        n_no_sa = int(((meta & 128) != 0).sum())
+        n_wide_rec = int(((meta & 64) != 0).sum())
+        uniq = (meta & 1) != 0
+        multi_m = (meta & 4) != 0
+        plain_res = torch.zeros((n_reads, 4), dtype=torch.int64, device=dev)
+        plain_res[:, 0] = w0 & m40
+        plain_res[:, 1] = (w0 & m40) + ((w0 >> 40) & 0xFFFFFF)
+        idx = torch.arange(n_reads, device=dev, dtype=torch.int64)
+        nh_t = torch.where(uniq, torch.ones_like(idx), torch.where(multi_m, (w1 >> 40) & 0xFFFF, torch.zeros_like(idx)))
+        plain_res[:, 2] = torch.where(uniq, idx, torch.where(multi_m & (nh_t > 0), n_reads + (w1 & m40), torch.zeros_like(idx)))
+        plain_res[:, 3] = nh_t | (((meta >> 3) & 3) << 32)
+        plain_hits = torch.zeros((n_reads + int(n_hits), 2), dtype=torch.int64, device=dev)
+        plain_hits[:n_reads, 0] = torch.where(uniq, w1 & m40, torch.zeros_like(idx))
+        plain_hits[:n_reads, 1] = torch.where(uniq, ((w1 >> 40) & 0xFFFF) | (((meta >> 1) & 1) << 32), torch.zeros_like(idx))
+        if n_hits:
+            plain_hits[n_reads:] = hits.view(torch.int64).view(-1, 2)[: int(n_hits)]
+        del rec, w0, w1, idx, nh_t
+        if args.layout == "hits":
+            # reads settled without an SA interval: the origin check below expects a size-1 interval for a hit
+            no_sa = (meta & 128) != 0
+            plain_res[:, 1] = torch.where(no_sa & uniq, plain_res[:, 0] + 1, plain_res[:, 1])
+        results_plain = plain_res.view(-1).view(torch.uint8)
+        hits_plain = plain_hits.view(-1).view(torch.uint8)
+    else:
+        n_no_sa = n_wide_rec = 0
+        results_plain, hits_plain = results, hits
+        n_hits = n_hits - n_reads if n_hits >= n_reads else 0      # lists only, as in the compact layouts
     origin = None
     if origins is not None:
-        origin = origin_check(torch, dev, results, hits, origins, L, chr_start, npos_key, npos_val)
+        origin = origin_check(torch, dev, results_plain, hits_plain, origins, L, chr_start, npos_key, npos_val)
         del origins
     value = world * n_reads * args.steps / elapsed
     search_ms = float(np.mean([k[1] for k in kernel_ms]))
     multi_ms = float(np.mean([k[2] for k in kernel_ms]))
-    res_np = np.frombuffer(results.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
+    res_np = np.frombuffer(results_plain.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
     mapped = int((res_np["nh"] > 0).sum())
-    multi = int(((res_np["sa_hi"] - res_np["sa_lo"]) > 1).sum())
+    multi = int((res_np["nh"] > 1).sum())
+    no_sa_np = None
+    if args.layout == "hits":
+        no_sa_np = ((results.view(torch.int64).view(-1, 2)[:20000, 1] >> 56) & 128).cpu().numpy() != 0
     # Algorithmic bytes of ONE k_search_sm launch: the search is a chain of random accesses
     # into index tables far larger than any cache, and HBM serves such an access as one 128-byte line whatever
     # part of it is used, so the unit is the line: 128 B x (index lines the reads of the batch need, counted by
@@ -463,7 +513,8 @@ def main():
     # + the streamed bytes (read record + length in, result + hit out).
     stats = ctx.last_stats_ex()
     accesses = int(stats[0])
-    streamed = n_reads * (wpr * 4 + 4 + 32) + int(n_hits) * 16
+    out_bytes = 16 if compact else 48     # per read: one 16-byte record, or a 32-byte record + the 16-byte hit slot
+    streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(n_hits) * 16
     algo_bytes = 128 * accesses + streamed
     achieved = algo_bytes / (search_ms * 1e-3) / 1e9
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
@@ -514,16 +565,19 @@ def main():
         rate1 = probe_n / (time.perf_counter() - t1)
         # parity of the same reads through the GPU path
         gres = res_np[:probe_n]
-        ok = bool(np.array_equal(gres["sa_lo"], lo) and np.array_equal(gres["sa_hi"], hi) and np.array_equal(gres["nh"], nh))
+        sa_ok = np.ones(probe_n, bool) if no_sa_np is None else ~no_sa_np[:probe_n]
+        ok = bool(np.array_equal(gres["sa_lo"][sa_ok], lo[sa_ok]) and np.array_equal(gres["sa_hi"][sa_ok], hi[sa_ok])
+                  and np.array_equal(gres["nh"], nh))
         if ok and int(nh.sum()):
             # ordered hit lists of the probe reads, gathered on the device (the lists of multi-hit reads lie anywhere)
             tot = int(nh.sum())
             within = np.arange(tot) - np.repeat(np.cumsum(nh) - nh, nh)
             gi = torch.from_numpy((np.repeat(gres["first_hit"], nh) + within).astype(np.int64)).to(dev)
-            ghits = np.frombuffer(hits.view(-1, 16)[gi].cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
+            ghits = np.frombuffer(hits_plain.view(-1, 16)[gi].cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
             oi = (np.repeat(first, nh) + within).astype(np.int64)
             ok = bool(np.array_equal(ghits, ohits[oi]))
-        parity = {"reads_checked": probe_n, "identical": ok}
+        parity = {"reads_checked": probe_n, "identical": ok,
+                  "compared": "NH and ordered hit lists of every read; SA intervals of the %d reads that report one" % int(sa_ok.sum())}
         sample_n = int(min(sample_max, host_lens.size, max(probe_n, rate1 * cores * args.cpu_seconds * 0.7)))
         seqs, offsets = unpack_reads(host_packed[:sample_n], host_lens[:sample_n])
         t1 = time.perf_counter()
@@ -542,22 +596,30 @@ def main():
             # page-locked memory (PCIe both ways), (b) FASTQ file -> SAM file with 16 host threads
             from sbwt_amd import api
             n_e = int(min(n_reads, 16_000_000))
-            pin = api.PinnedBuffer(n_e * (wpr * 4 + 4 + 32 + 2 * 16))
+            pin = api.PinnedBuffer(n_e * (wpr * 4 + 4 + 32 + 2 * 16) + n_e * 16 + (1 << 20) * 16 + 1024 * 48)
             o = 0
             pk = pin.array(np.uint32, n_e * wpr, o); o += n_e * wpr * 4
             ln = pin.array(np.uint32, n_e, o); o += n_e * 4
             rs = pin.array(api.RESULT_DTYPE, n_e, o); o += 32 * n_e
-            ht = pin.array(api.HIT_DTYPE, 2 * n_e, o)
+            ht = pin.array(api.HIT_DTYPE, 2 * n_e, o); o += 32 * n_e
+            cr = pin.array(api.COMPACT_DTYPE, n_e, o); o += 16 * n_e
+            cl = pin.array(api.HIT_DTYPE, 1 << 20, o); o += 16 << 20
+            cw = pin.array(api.WIDE_DTYPE, 1024, o)
             pk[:] = packed[:n_e].cpu().numpy().view(np.uint32).reshape(-1)
             ln[:] = lens[:n_e].cpu().numpy().astype(np.uint32)
             ctx_e = sbwt_amd.Context(ix, n_e)
-            best = None
+            best = best_c = None
             if not many_hits:
                 for _ in range(3):
                     t1 = time.perf_counter()
                     ctx_e.map_batch(pk.reshape(n_e, wpr), ln, out=(rs, ht))
                     dt = time.perf_counter() - t1
                     best = dt if best is None or dt < best else best
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ctx_e.map_batch_compact(pk.reshape(n_e, wpr), ln, mode=sbwt_amd.MAP_HITS_ONLY, out=(cr, cl, cw))
+                    dt = time.perf_counter() - t1
+                    best_c = dt if best_c is None or dt < best_c else best_c
             n_f = int(min(n_e, 8_000_000))
             tmpd = tempfile.mkdtemp(prefix="sbwt_bench_")
             fq, sam = os.path.join(tmpd, "r.fq"), os.path.join(tmpd, "o.sam")
@@ -569,12 +631,14 @@ def main():
                 dt = time.perf_counter() - t1
                 fbest = dt if fbest is None or dt < fbest else fbest
             sam_bytes = os.path.getsize(sam)
-            del pk, ln, rs, ht
+            del pk, ln, rs, ht, cr, cl, cw
             ctx_e.close()
             pin.close()
             shutil.rmtree(tmpd, ignore_errors=True)
-            end_to_end = {"host_buffers_reads_per_s": round(n_e / best, 1) if best else None, "host_buffers_reads": n_e,
-                          "host_buffers_note": "sbwt_map_batch, page-locked host buffers: H2D of packed reads, kernels, D2H of results + hits",
+            end_to_end = {"host_buffers_reads_per_s": round(n_e / best_c, 1) if best_c else None, "host_buffers_reads": n_e,
+                          "host_buffers_note": "sbwt_map_batch_compact (hits only), page-locked host buffers: H2D of packed reads (20 B per "
+                                               "read), kernels, D2H of the 16-byte records",
+                          "host_buffers_plain_layout_reads_per_s": round(n_e / best, 1) if best else None,
                           "fastq_to_sam_reads_per_s": round(n_f / fbest, 1), "fastq_to_sam_reads": n_f, "host_threads": cores,
                           "fastq_MB": round(fq_bytes / 1e6), "sam_MB": round(sam_bytes / 1e6), "sam_records": int(st[4])}
         if not args.no_extras and plain and args.scale == 1.0:
@@ -595,10 +659,17 @@ def main():
                    "index_suffixes": int(info.n), "index_hbm_GB": round(info.device_bytes / 1e9, 2),
                    "search_prefix_tables": {"direct_order": int(info.kmer_order), "hash_order": int(info.hash_order)},
                    "suffix_order": "stopped at sort_len 256, ties shuffled" if args.shuffle_ties else "full",
+                   "result_layout": {"plain": "32-byte record + 16-byte hit slot per read (sbwt_map_batch_device)",
+                                     "compact": "16-byte record per read (sbwt_map_batch_device_compact)",
+                                     "hits": "16-byte record per read, SBWT_MAP_HITS_ONLY: hits, NH and flags of every read; no SA interval "
+                                             "for reads their located prefix settles (what the SAM output needs)"}[args.layout],
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": config1,
-        "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "hits": int(n_hits),
+        "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "list_hits": int(n_hits), "wide_records": n_wide_rec,
+                   "reads_without_sa_interval": n_no_sa,
                    "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
+                   "k_settle_ms": round(float(np.mean([k[3] for k in kernel_ms])), 3),
+                   "pending_pass_ms": round(float(np.mean([k[4] for k in kernel_ms])), 3),
                    "setup_s": {"genome": round(t_genome, 1), "index_build": round(t_index, 1), "reads": round(t_reads, 1)},
                    "parity_vs_oracle": parity, "origin_check": origin},
     }

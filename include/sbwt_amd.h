@@ -94,6 +94,7 @@ typedef struct sbwt_index_info {
   int device;
   uint32_t kmer_order;     /* bases the direct search-prefix table memoises (12 = none: c_functions only) */
   uint32_t hash_order;     /* bases the hash table of located prefixes covers (0 = none) */
+  uint32_t hash_text;      /* 1: its slots carry the 32 bases of text behind the prefix (SBWT_MAP_HITS_ONLY fast pass) */
 } sbwt_index_info;
 
 const char *sbwt_last_error(void);
@@ -237,6 +238,9 @@ void sbwt_host_free(void *p);
 /* Milliseconds the kernels of the last sbwt_map_batch* call on this ctx took, measured with HIP events
  * on the ctx stream: [0] whole device pass, [1] search+unique-locate kernel, [2] multi-hit locate. */
 int sbwt_ctx_last_timing(const sbwt_ctx *ctx, float ms[3]);
+/* The same and more: [0..2] as above, [3] the hits-only fast pass (k_settle) of a compact call, [4] the general
+ * kernels over the reads it left pending ([1] = [3] + their search kernel); values beyond read 0. */
+int sbwt_ctx_last_timing_ex(const sbwt_ctx *ctx, float *ms, uint32_t n);
 /* Counters of the last sbwt_map_batch* call on this ctx: [0] random index accesses the search kernel needed
  * (one per 128-byte line of an index table; the unit of the gather roofline), [1] reads handed to
  * the multi-hit locate, [2] hit slots in use, [3] multi-hit reads that needed the depth-first walk.  No upstream counterpart: measurement only. */

@@ -30,7 +30,7 @@ class IndexInfo(C.Structure):
     _fields_ = [("n", C.c_uint64), ("real_size", C.c_uint64), ("interval", C.c_uint64),
                 ("first_location", C.c_uint64), ("n_chr", C.c_uint64), ("n_npos", C.c_uint64),
                 ("n_loc", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int),
-                ("kmer_order", C.c_uint32), ("hash_order", C.c_uint32)]
+                ("kmer_order", C.c_uint32), ("hash_order", C.c_uint32), ("hash_text", C.c_uint32)]
 
 
 class HostTables(C.Structure):
@@ -120,6 +120,7 @@ def lib():
     L.sbwt_host_free.restype = None
     L.sbwt_ctx_last_timing.argtypes = [vp, p(C.c_float * 3)]
     L.sbwt_ctx_last_stats.argtypes = [vp, p(u64 * 4)]
+    L.sbwt_ctx_last_timing_ex.argtypes = [vp, p(C.c_float * 5), u32]
     L.sbwt_ctx_last_stats_ex.argtypes = [vp, p(u64 * 8), u32]
     L.sbwt_probe_random_access.argtypes = [vp, u32, u32, u32, p(C.c_double), p(u64)]
     L.sbwt_ctx_stream.argtypes = [vp]
@@ -392,6 +393,11 @@ class Context:
         st = (C.c_uint64 * 4)()
         _check(lib().sbwt_ctx_last_stats(self._h, C.byref(st)))
         return list(st)
+
+    def last_timing_ex(self):
+        ms = (C.c_float * 5)()
+        _check(lib().sbwt_ctx_last_timing_ex(self._h, C.byref(ms), 5))
+        return list(ms)
 
     def last_stats_ex(self):
         st = (C.c_uint64 * 8)()

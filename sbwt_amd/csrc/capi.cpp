@@ -203,6 +203,7 @@ extern "C" int sbwt_index_get_info(const sbwt_index* ix, sbwt_index_info* info) 
   info->device = ix->device;
   info->kmer_order = ix->d.kmer_order;
   info->hash_order = ix->d.hash_order;
+  info->hash_text = ix->d.hash_text;
   return SBWT_OK;
 }
 

@@ -752,7 +752,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     const char* fail_alloc = getenv("SBWT_DEBUG_FAIL_TABLE_ALLOC");  // "hash", "kmer" or "both"
     const bool fail_hash = fail_alloc && (!strcmp(fail_alloc, "hash") || !strcmp(fail_alloc, "both"));
     const bool fail_kmer = fail_alloc && (!strcmp(fail_alloc, "kmer") || !strcmp(fail_alloc, "both"));
-    constexpr uint64_t kKmerHeadroom = 24ull << 30;
+    constexpr uint64_t kKmerHeadroom = 16ull << 30;  // batches, scratch; the raw tables still resident here (12 GB at GRCh38 size) are freed after the load
     // hash table of located order-20 prefixes (device_layout.h): 1.6 slots per suffix, on indexes of 2^22 suffixes
     // or more when it fits next to an order-16 direct table; SBWT_HASH_ORDER overrides (0 = none)
     uint32_t H = raw.n >= (1ull << 22) ? 20u : 0u;

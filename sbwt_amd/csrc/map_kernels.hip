@@ -24,6 +24,7 @@
 #include "rank_device.h"
 #include "search_machine.h"
 #include "multi_locate.h"
+#include "settle.h"
 
 namespace sbwt {
 
@@ -36,6 +37,8 @@ struct Counters {
   unsigned long long dfs_count;       // multi-hit reads k_multi_sort handed on to the depth-first kernel
   unsigned long long hash_stats[2];   // hash_tab lookups of k_search_sm, and those that found their prefix
   unsigned long long wide_count;      // compact output: results that went to wide[]
+  unsigned long long pending_count;   // k_settle: reads left to the general kernels
+  unsigned long long pending_other;   // ... of which not because their prefix is missing from hash_tab
 };
 
 struct MapArgs {
@@ -158,6 +161,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
 constexpr int kNumStats = 6;  // sbwt_ctx_last_stats_ex
+constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
   hipStream_t stream = nullptr;
@@ -189,6 +193,14 @@ struct sbwt_ctx : MapWork {
   sbwt_hit* d_hits = nullptr;
   sbwt_wide_result* d_wide = nullptr;
   uint64_t staged_words = 0, staged_reads = 0, staged_hits = 0, staged_wide = 0;
+  // hits-only fast pass (settle.h): the list of pending reads, and their dense batch (grown on demand)
+  uint32_t* d_pend_list = nullptr;  // max_reads entries
+  uint32_t *d_pend_packed = nullptr, *d_pend_lens = nullptr;
+  sbwt_compact_result* d_pend_out = nullptr;
+  uint64_t pend_words = 0, pend_lens_cap = 0, pend_out_cap = 0;
+  hipEvent_t ev_s[2] = {nullptr, nullptr};
+  uint32_t grid_settle = 0;
+  float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
 };
 
 // Launch shapes of the kernels for this index on its device: resident workgroups per kernel variant and the LDS
@@ -232,6 +244,15 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, sizeof(Counters));
   if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&c->d_dfs_queue, max_reads * sizeof(uint32_t));
+  if (e == hipSuccess && ix->d.hash_text) e = hipMalloc(&c->d_pend_list, max_reads * sizeof(uint32_t));
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev_s[k]);
+  if (e == hipSuccess) {
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_settle, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, ix->device);
+    if (e == hipSuccess) c->grid_settle = (uint32_t)(prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1));
+  }
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
   c->multi_lanes = 256u * 1024u;
   if (c->multi_lanes > max_reads) c->multi_lanes = (uint32_t)((max_reads + 255) / 256 * 256);
@@ -263,6 +284,9 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_wave_info);
   hipFree(c->d_stacks);
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits); hipFree(c->d_wide);
+  hipFree(c->d_pend_list); hipFree(c->d_pend_packed); hipFree(c->d_pend_lens); hipFree(c->d_pend_out);
+  for (int k = 0; k < 2; ++k)
+    if (c->ev_s[k]) hipEventDestroy(c->ev_s[k]);
   for (int k = 0; k < 3; ++k)
     if (c->ev[k]) hipEventDestroy(c->ev[k]);
   for (int k = 0; k < 2; ++k)
@@ -288,6 +312,12 @@ extern "C" int sbwt_ctx_last_stats(const sbwt_ctx* c, uint64_t stats[4]) {
 extern "C" int sbwt_ctx_last_stats_ex(const sbwt_ctx* c, uint64_t* stats, uint32_t n) {
   if (!c || (!stats && n)) return SBWT_ERR_ARG;
   for (uint32_t k = 0; k < n; ++k) stats[k] = k < (uint32_t)kNumStats ? c->last_stats[k] : 0;
+  return SBWT_OK;
+}
+
+extern "C" int sbwt_ctx_last_timing_ex(const sbwt_ctx* c, float* ms, uint32_t n) {
+  if (!c || (!ms && n)) return SBWT_ERR_ARG;
+  for (uint32_t k = 0; k < n; ++k) ms[k] = k < 3 ? c->last_ms[k] : (k < 5 ? c->last_ms_ex[k - 3] : 0.f);
   return SBWT_OK;
 }
 
@@ -385,7 +415,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     sa.wide = io.wide;
     sa.wide_cap = io.wide_cap;
     sa.wide_count = &w.d_ctr->wide_count;
-    sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
+    sa.skip_hash = (mode & kModeSkipHash) ? 1u : 0u;
     sa.hits = d_hits;
     sa.hits_cap = hits_cap;
     sa.multi_queue = w.d_queue;
@@ -473,6 +503,92 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
   return SBWT_OK;
 }
 
+template <typename T>
+static int ensure(T** p, uint64_t* have, uint64_t need);
+
+// One device pass with compact records.  Hits only, on an index whose hash slots carry text, records of 64 bases:
+// k_settle first (one access per read), then the general kernels over the reads it left pending, gathered into a
+// dense batch; otherwise the general kernels alone.
+static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads, uint32_t words_per_read,
+                            int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits, uint64_t hits_cap,
+                            uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate) {
+  const DeviceIndex& d = c->ix->d;
+  const bool settle = (mode & SBWT_MAP_HITS_ONLY) && d.hash_text && d.hash_order && words_per_read == 4 && c->d_pend_list &&
+                      !getenv("SBWT_NO_SETTLE");
+  if (!settle) {
+    if (!accumulate) c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
+    return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, multi_base,
+                    multi_used, wide_used, accumulate, c->last_ms, c->last_stats);
+  }
+  SettleArgs sa;
+  sa.packed = d_packed;
+  sa.lens = d_lens;
+  sa.n_reads = n_reads;
+  sa.strand = strand;
+  sa.limit = (uint64_t)(int64_t)limit;
+  sa.out = io.compact;
+  sa.pending_list = c->d_pend_list;
+  sa.pending_count = &c->d_ctr->pending_count;
+  sa.index_accesses = &c->d_ctr->index_accesses;
+  sa.hash_stats = c->d_ctr->hash_stats;
+  sa.pending_other = &c->d_ctr->pending_other;
+  sa.lds_tables = c->sort_lds_bytes ? 1u : 0u;
+  sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
+  SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+  SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, c->grid_settle);
+  k_settle<<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  SBWT_LAUNCHED();
+  SBWT_HIP(hipEventRecord(c->ev_s[1], c->stream));
+  SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+  SBWT_HIP(hipStreamSynchronize(c->stream));
+  const uint64_t n_pending = c->h_ctr->pending_count;
+  const bool all_missed = c->h_ctr->pending_other == 0;  // then the general kernels skip the hash table for this batch
+  const uint64_t s_acc = c->h_ctr->index_accesses, s_look = c->h_ctr->hash_stats[0], s_found = c->h_ctr->hash_stats[1];
+  float ms_settle = 0.f;
+  hipEventElapsedTime(&ms_settle, c->ev_s[0], c->ev_s[1]);
+  int rc = SBWT_OK;
+  *multi_used = 0;
+  if (wide_used) *wide_used = 0;
+  float ms_pending = 0.f;
+  if (n_pending) {
+    if (c->pend_out_cap < n_pending) {  // grown with a quarter to spare, so that batches of similar make-up reuse it
+      const uint64_t want = std::min<uint64_t>(c->max_reads, n_pending + (n_pending >> 2));
+      if (int e = ensure(&c->d_pend_packed, &c->pend_words, want * 4)) return e;
+      if (int e = ensure(&c->d_pend_lens, &c->pend_lens_cap, want)) return e;
+      if (int e = ensure(&c->d_pend_out, &c->pend_out_cap, want)) return e;
+    }
+    k_gather_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(d_packed, d_lens, c->d_pend_list, n_pending, c->d_pend_packed,
+                                                                         c->d_pend_lens);
+    SBWT_LAUNCHED();
+    const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
+    float ms3[3] = {0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0};
+    rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, 4, limit, strand, io2,
+                  mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
+                  multi_used, wide_used, false, ms3, st);
+    if (rc != SBWT_OK && rc != SBWT_ERR_CAPACITY) return rc;
+    k_scatter_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(c->d_pend_out, c->d_pend_list, n_pending, io.compact);
+    SBWT_LAUNCHED();
+    SBWT_HIP(hipStreamSynchronize(c->stream));
+    ms_pending = ms3[0];
+    const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
+    for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5]};
+    for (int k = 0; k < kNumStats; ++k)
+      if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
+  } else {
+    const float add[3] = {ms_settle, ms_settle, 0.f};
+    for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found};
+    for (int k = 0; k < kNumStats; ++k)
+      if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
+  }
+  c->last_ms_ex[0] = (accumulate ? c->last_ms_ex[0] : 0.f) + ms_settle;
+  c->last_ms_ex[1] = (accumulate ? c->last_ms_ex[1] : 0.f) + ms_pending;
+  return rc;
+}
+
 extern "C" int sbwt_map_batch_device_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                                              uint32_t words_per_read, int limit, int strand, uint32_t mode,
                                              sbwt_compact_result* d_out, sbwt_hit* d_hits, uint64_t hits_cap,
@@ -490,8 +606,8 @@ extern "C" int sbwt_map_batch_device_compact(sbwt_ctx* c, const uint32_t* d_pack
   SBWT_HIP(hipSetDevice(c->ix->device));
   const ResultIO io{nullptr, d_out, d_wide, wide_cap};
   uint64_t multi_used = 0, wide_used = 0;
-  const int rc = map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, 0,
-                          &multi_used, &wide_used, false, c->last_ms, c->last_stats);
+  const int rc = map_pass_compact(c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, 0,
+                                  &multi_used, &wide_used, false);
   c->last_stats[2] = multi_used;
   if (counts_host) {  // on SBWT_ERR_CAPACITY: what a retry needs
     counts_host[0] = multi_used;
@@ -808,8 +924,8 @@ extern "C" int sbwt_map_batch_compact(sbwt_ctx* c, const uint32_t* packed, const
     // the lists of this piece go behind those of the pieces before it; its wide slots likewise
     const ResultIO io{nullptr, d_out + a0, c->d_wide + std::min(used_wide, wide_cap), wide_cap - std::min(used_wide, wide_cap)};
     uint64_t mu = 0, wu = 0;
-    const int prc = map_pass(c->ix, *c, c->d_packed + a0 * words_per_read, c->d_lens + a0, n0, words_per_read, limit, strand, io,
-                             mode, c->d_hits, hits_cap, used_multi, &mu, &wu, a0 != 0, c->last_ms, c->last_stats);
+    const int prc = map_pass_compact(c, c->d_packed + a0 * words_per_read, c->d_lens + a0, n0, words_per_read, limit, strand, io,
+                                     mode, c->d_hits, hits_cap, used_multi, &mu, &wu, a0 != 0);
     if (prc != SBWT_OK && prc != SBWT_ERR_CAPACITY) { rc = prc; break; }
     if (prc == SBWT_ERR_CAPACITY) rc = prc;  // keep counting: the caller learns what the whole batch needs
     if (rc == SBWT_OK) {

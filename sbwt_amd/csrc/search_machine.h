@@ -143,7 +143,7 @@ struct SmArgs {
   sbwt_wide_result* wide;
   unsigned long long* wide_count;
   uint64_t wide_cap;
-  uint32_t hits_only;  // SBWT_MAP_HITS_ONLY: the SA interval of a read the located-prefix text settles is not needed
+  uint32_t skip_hash;  // the batch holds only reads whose prefix is known not to be in hash_tab (k_settle looked them up)
 };
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
@@ -223,7 +223,6 @@ constexpr uint32_t A_CUR_KH = 1u << 22;   // ... which came from hash_tab: a loc
 constexpr uint32_t A_CUR_P2 = 1u << 23;   // (long-read variant) w2 holds the 64-base piece after the one in w
 constexpr uint32_t A_REQ_P2 = 1u << 25;   // (long-read variant) ... and is on its way with the next piece
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
-constexpr uint32_t A_SETTLED = 1u << 26;  // (hits only) the text in the hash slot settled the read: hit at p, or dead; no SA interval
 
 // prefetch pipeline of a lane: its next read (1) and the one after (2)
 constexpr uint32_t PF_W1 = 1u, PF_K1 = 2u, PF_W2 = 4u;        // record of 1, prefix entry of 1, record of 2 are here
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   const uint64_t range_begin = wave * chunk;
   const uint64_t range_end = range_begin + chunk < a.n_reads ? range_begin + chunk : a.n_reads;
   const uint32_t K = ix.kmer_order;
-  const uint32_t H = ix.hash_order;  // 0: no hash table
+  const uint32_t H = a.skip_hash ? 0u : ix.hash_order;  // 0: no hash table
   const uint64_t hmask = (1ull << (2 * H)) - 1ull;
   const uint64_t kmask = (1ull << (2 * K)) - 1ull;  // K <= kMaxKmerOrder: the prefix lies in the first 32 bases, w_lo
   const uint32_t max_len = a.wpr * 16u;
@@ -285,36 +284,16 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0, mL = 0, pf = 0;
   uint64_t lo = 0, hi = 0, w_lo = 0, w_hi = 0, p = 0, t_lo = 0, t_hi = 0;
   uint64_t ck = 0;                                     // prefix entry of the read about to start
-  uint64_t ckt = 0, nkt = 0;                           // (hash_text) the 32 bases of text behind the located prefix of r, of rn
   uint64_t nw_lo = 0, nw_hi = 0, nk = 0, mw_lo = 0, mw_hi = 0;  // records of rn (with its prefix entry) and rn2
   uint64_t w2_lo = 0, w2_hi = 0, nw2_lo = 0, nw2_hi = 0;        // kLong: bases 64..127 of the current read and of rn
 
   // interval after the search prefix, from a kmer_tab entry (device_layout.h)
-  const bool kInline = a.hits_only && ix.hash_text;  // wave-uniform
-  auto apply_prefix = [&](uint64_t e, uint32_t Kp, bool from_hash) {  // Kp = bases the entry covers (kmer_order, or hash_order)
+  auto apply_prefix = [&](uint64_t e, uint32_t Kp) {  // Kp = bases the entry covers (kmer_order, or hash_order)
     uint64_t width = e >> kPosBits;
     if (e & kKmerLocated) {
       // one row, already located: straight to the text comparison when it can carry the rest of the read
       const uint64_t pos = e & kPosMask, run = (e >> kPosBits) & kKmerRunMax;
       const uint64_t rem = (uint64_t)L - Kp;
-      if (kInline && from_hash && rem >= 1 && rem <= 32 && run > rem && pos >= rem) {
-        // hits only: the prefix is ONE located row, so the rest of the read either equals the text in front of it
-        // (the one hit, rem positions further down) or the interval dies; the slot carries those 32 bases of text
-        uint64_t r0, r1;
-        sm_funnel128(w_lo, w_hi, 0, 0, Kp, r0, r1);
-        const uint64_t diff = (r0 ^ ckt) & (rem < 32 ? (1ull << (2 * rem)) - 1ull : ~0ull);
-        aux |= A_TRIED | A_SETTLED;
-        if (diff == 0) {
-          p = pos - rem;
-          j = L;
-          lo = 0;
-          hi = 1;
-          aux |= A_LOCATED;
-        } else {
-          lo = hi = 0;
-        }
-        return;
-      }
       if (rem >= 1 && run > rem && pos >= rem) {
         p = pos;
         j = Kp;
@@ -343,7 +322,6 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       st = S_CMP;
       return false;
     }
-    if (aux & A_SETTLED) return true;
     if (lo >= hi || j >= L) return true;
     if ((j & 63u) == 0 && j >= 64u && !(aux & A_PIECE)) {
       aux |= A_PIECE;  // w must hold the piece j is in before anything looks at the next bases
@@ -394,7 +372,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = hi = 0;
           st = S_FIN;
         } else if (had & A_CUR_K) {
-          apply_prefix(ck, (had & A_CUR_KH) ? ix.hash_order : K, (had & A_CUR_KH) != 0);
+          apply_prefix(ck, (had & A_CUR_KH) ? ix.hash_order : K);
           if (choose()) st = S_FIN;
         } else {
           st = S_KMER;
@@ -591,9 +569,14 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint64_t vc = *pc, ve = *pe, vk = *pk, vl = *pl;
     const uint32_t vd = *pd;
     uint4 vh0 = make_uint4(0, 0, 0, 0), vh1 = vh0;
-    uint4 vh2 = vh0, vh3 = vh0;
-    if (H) { vh0 = ph[0]; vh1 = ph[1]; }  // wave-uniform condition
-    if (H && ix.hash_text) { vh2 = ph[2]; vh3 = ph[3]; }  // 16-byte slots: position word + 32 bases of text
+    if (H && !ix.hash_text) { vh0 = ph[0]; vh1 = ph[1]; }  // wave-uniform conditions; 8-byte slots: the bucket in two loads
+    if (H && ix.hash_text) {
+      // 16-byte slots (position word + the text k_settle compares): the four position words, 8 bytes each
+      const uint64_t* pw = reinterpret_cast<const uint64_t*>(ph);
+      const uint64_t q0 = pw[0], q1 = pw[2], q2 = pw[4], q3 = pw[6];
+      vh0 = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
+      vh1 = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
+    }
     uint4 vr2 = make_uint4(0, 0, 0, 0);
     if (kLong) vr2 = *pr2;
     __builtin_amdgcn_wave_barrier();
@@ -623,14 +606,12 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       const uint64_t vv = hash_mix((~nw_lo) & hmask, H);
       // (tag in the low word; the high word of an empty slot is all ones, that of a position never is)
       const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u, tag = (uint32_t)vv & tmask;
-      const bool wide_slots = ix.hash_text != 0;  // wave-uniform
-      const uint32_t sl_lo[4] = {vh0.x, wide_slots ? vh1.x : vh0.z, wide_slots ? vh2.x : vh1.x, wide_slots ? vh3.x : vh1.z};
-      const uint32_t sl_hi[4] = {vh0.y, wide_slots ? vh1.y : vh0.w, wide_slots ? vh2.y : vh1.y, wide_slots ? vh3.y : vh1.w};
-      const uint64_t sl_tx[4] = {u64_of(vh0.z, vh0.w), u64_of(vh1.z, vh1.w), u64_of(vh2.z, vh2.w), u64_of(vh3.z, vh3.w)};
+      const uint32_t sl_lo[4] = {vh0.x, vh0.z, vh1.x, vh1.z};
+      const uint32_t sl_hi[4] = {vh0.y, vh0.w, vh1.y, vh1.w};
       uint64_t found = ~0ull;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) { found = u64_of(sl_lo[q], sl_hi[q]); nkt = sl_tx[q]; }
+        if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) found = u64_of(sl_lo[q], sl_hi[q]);
       pf = (pf | PF_H1) & ~PF_RH1;
       tally_h += 0x10000u + (found != ~0ull ? 1u : 0u);
       if (found != ~0ull) {
@@ -662,7 +643,7 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
           lo = vc;
           hi = ve;
         } else {
-          apply_prefix(vc, K, false);
+          apply_prefix(vc, K);
         }
         finish = choose();
         break;
@@ -889,10 +870,6 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       }
       // flags: bits 0..1 and bit 31 are in use
       meta |= ((flags & 3u) << R_FLAGS_SHIFT) | ((flags & kFlagInvalid) ? R_INVALID : 0u);
-      if (aux & A_SETTLED) {  // no SA interval was computed (hits only)
-        meta |= R_NOSA;
-        lo = hi = 0;
-      }
       uint64_t width = hi - lo;
       if (hi < lo || width >= a.ring_width_max || chr_id > a.ring_chr_max || payload > kPosMask ||
           (a.compact && want > 0xFFFFull)) {  // (compact: the entry of a multi-hit read carries NH in 16 bits)
@@ -928,7 +905,6 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       w_hi = nw_hi;
       L = nL;
       ck = nk;
-      ckt = nkt;
       nw_lo = mw_lo;
       nw_hi = mw_hi;
       nL = mL;

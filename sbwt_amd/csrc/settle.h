@@ -1,0 +1,232 @@
+// settle.h -- k_settle: the hits-only fast pass.
+//
+// With SBWT_MAP_HITS_ONLY the caller wants what the SAM output needs -- the hits, NH and flags of every read
+// (searcher.hpp:386-458 returns nothing else) -- not the SA interval.  On an index whose hash slots carry the text
+// behind the located prefix (device_layout.h, hash_text) a read of hash_order + 1 .. hash_order + 32 bases whose
+// first hash_order bases are in the table is SETTLED by its bucket alone: that prefix is ONE located row, so under
+// exec_exact_match (searcher.hpp:102-105) the remaining bases either equal the text in front of the row's position
+// (the interval stays that one row's LF chain: one hit, `rem` positions further down) or the interval dies.  One
+// random access per read, no dependent chain: a streaming kernel, one read per lane, instead of the state machine.
+//
+// Everything else -- prefix not in the table, run of LF-consistent positions too short, a read of another length, a
+// result no 16-byte record holds -- is left PENDING: its index goes to a list, the host gathers those reads into a
+// dense batch and the general kernels (k_search_sm, k_multi_sort, k_multi) map it exactly as they map any batch;
+// k_scatter_pending puts their records in place.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sbwt_amd.h"
+#include "rank_device.h"
+#include "search_machine.h"
+
+namespace sbwt {
+
+struct SettleArgs {
+  const uint32_t* packed;  // records of 4 words (64 bases)
+  const uint32_t* lens;
+  uint64_t n_reads;
+  int strand;
+  uint64_t limit;
+  sbwt_compact_result* out;
+  uint32_t* pending_list;               // read indices left to the general kernels
+  unsigned long long* pending_count;
+  unsigned long long* index_accesses;   // += buckets read
+  unsigned long long* hash_stats;       // [0] lookups, [1] found
+  unsigned long long* pending_other;    // pending reads that were not looked up and missed (long, short run, wide result)
+  uint32_t lds_tables;                  // the launch carries (n_chr + 2 n_npos) * 8 bytes of LDS for the filter tables
+  uint32_t ring_chr_max;                // chr_id a record holds (test knob, as in SmArgs)
+};
+
+// DPP moves inside a quad (lanes 4q .. 4q+3): full-rate VALU, no LDS
+template <int kSrc>
+__device__ __forceinline__ uint32_t quad_bcast_t(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kSrc * 0x55, 0xF, 0xF, true);  // quad_perm [k,k,k,k]
+}
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int k) {
+  switch (k) {
+    case 0: return quad_bcast_t<0>(v);
+    case 1: return quad_bcast_t<1>(v);
+    case 2: return quad_bcast_t<2>(v);
+    default: return quad_bcast_t<3>(v);
+  }
+}
+__device__ __forceinline__ uint32_t quad_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // [1,0,3,2]
+__device__ __forceinline__ uint32_t quad_swap2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }  // [2,3,0,1]
+
+constexpr uint32_t kSettleBuf = 512;  // pending indices a wave holds in LDS before it reserves list slots for them
+
+__global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const SettleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
+  const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
+  if (a.lds_tables) {
+    uint64_t* s_chr = s_tab;
+    uint64_t* s_nk = s_chr + ix.n_chr;
+    uint64_t* s_nv = s_nk + ix.n_npos;
+    for (uint32_t k = threadIdx.x; k < ix.n_chr; k += blockDim.x) s_chr[k] = ix.chr_start[k];
+    for (uint32_t k = threadIdx.x; k < ix.n_npos; k += blockDim.x) { s_nk[k] = ix.npos_key[k]; s_nv[k] = ix.npos_val[k]; }
+    __syncthreads();
+    t_chr = s_chr; t_nk = s_nk; t_nv = s_nv;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t H = ix.hash_order;
+  const uint64_t hmask = (1ull << (2 * H)) - 1ull;
+  const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint4* const recs = reinterpret_cast<const uint4*>(a.packed);
+  const uint4* const tab = reinterpret_cast<const uint4*>(ix.hash_tab);
+  // pending read indices collect per wave in LDS and leave in batches: one atomic on the shared counter per batch
+  // (same-address atomics run at about 1.2e8 per second on this device; one per wave and step would cost more than the
+  // whole pass)
+  __shared__ uint32_t s_pend_all[4][kSettleBuf];
+  uint32_t* const s_pend = s_pend_all[threadIdx.x >> 6];
+  uint32_t n_buf = 0;  // wave-uniform
+  auto flush_pending = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(a.pending_count, (unsigned long long)n_buf);
+    base = ((unsigned long long)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = lane; k < n_buf; k += 64) a.pending_list[base + k] = s_pend[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    n_buf = 0;
+  };
+  uint32_t looked = 0, found_n = 0, other_n = 0;
+
+  // ONE load instruction per line.  A lane that reads its 64-byte bucket through four 16-byte loads makes the second
+  // to fourth wait in the vector cache behind the first one's miss (measured: TCP_PENDING_STALL_CYCLES over the whole
+  // run of the kernel, 0.035 lines per cycle and CU against the 0.078 of the random-access probe).  So the four lanes
+  // of a quad fetch one bucket together, 16 bytes each in the same instruction -- four instructions serve the four
+  // reads of the quad, each line touched by exactly one -- and DPP moves inside the quad bring every read its slot.
+  const uint32_t sub = lane & 3u;  // this lane's slot within a bucket; also its turn within the quad
+  const uint64_t n_round = (a.n_reads + 63) & ~63ull;  // whole waves stay in the loop together (ballots, DPP)
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = r < a.n_reads;
+  uint4 rec = make_uint4(0, 0, 0, 0);
+  uint32_t L = 0;
+  if (valid) { rec = recs[r]; L = a.lens[r]; }
+  for (; r < n_round; r += stride) {
+    // the record of the read after this one is on its way while this one's bucket is awaited
+    const uint64_t rn = r + stride;
+    const bool nvalid = rn < a.n_reads;
+    uint4 nrec = make_uint4(0, 0, 0, 0);
+    uint32_t nL = 0;
+    if (nvalid) { nrec = recs[rn]; nL = a.lens[rn]; }
+
+    const uint64_t w_lo = u64_of(rec.x, rec.y), w_hi = u64_of(rec.z, rec.w);
+    bool pending = valid;
+    uint64_t e1 = 0;  // record word 1; word 0 (the SA interval) is 0 for every read settled here
+    if (valid && (L < (uint32_t)kKmer || L > 64u)) {
+      e1 = (uint64_t)R_INVALID << 56;  // as k_search_sm reports a read its record cannot hold: nothing mapped
+      pending = false;
+    }
+    const uint32_t rem = L - H;
+    const bool look = pending && L > H && rem <= 32u;
+    const uint64_t vv = hash_mix((~w_lo) & hmask, H);
+    const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
+    const uint32_t tag = (uint32_t)vv & tmask;
+    if (look) ++looked;
+    // round k: the quad loads the bucket of its lane k, lane `sub` the slot `sub`
+    uint4 piece[4];
+    uint32_t want[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t b_lo = quad_bcast((uint32_t)bucket, k), b_hi = quad_bcast((uint32_t)(bucket >> 32), k);
+      want[k] = quad_bcast(look ? 1u : 0u, k);
+      piece[k] = make_uint4(~0u, ~0u, 0, 0);
+      if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
+    }
+    uint64_t slot = ~0ull, text = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t tag_k = quad_bcast(tag, k);
+      const bool hit = want[k] && ((piece[k].x ^ tag_k) & tmask) == 0 && piece[k].y != 0xFFFFFFFFu;
+      // at most one slot of a bucket carries the tag: OR the (masked) slot over the quad
+      uint32_t v0 = hit ? piece[k].x : 0u, v1 = hit ? piece[k].y : 0u, v2 = hit ? piece[k].z : 0u, v3 = hit ? piece[k].w : 0u;
+      uint32_t any = hit ? 1u : 0u;
+      v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); v2 |= quad_swap1(v2); v3 |= quad_swap1(v3); any |= quad_swap1(any);
+      v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
+      if (sub == (uint32_t)k && any) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
+    }
+    bool missed = false;  // looked up and not in the table: the general kernels need not look again
+    if (look) {
+      missed = slot == ~0ull;
+      if (!missed) {
+        ++found_n;
+        const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
+        if (run > (uint64_t)rem && pos >= (uint64_t)rem) {
+          // bases H .. L-1 of the read against the text behind the prefix (search_machine.h, S_CMP: same orientation)
+          uint64_t r0, r1;
+          sm_funnel128(w_lo, w_hi, 0, 0, H, r0, r1);
+          const uint64_t diff = (r0 ^ text) & (rem < 32u ? (1ull << (2 * rem)) - 1ull : ~0ull);
+          uint32_t meta = R_NOSA;
+          uint64_t payload = 0;
+          uint32_t chr_id = 0;
+          bool fits = true;
+          if (diff == 0) {  // raw interval of one row
+            if (1ull > a.limit) {
+              meta |= 1u << R_FLAGS_SHIFT;  // SBWT_RF_SUPPRESSED (searcher.hpp:415)
+            } else {
+              sbwt_hit h;
+              if (push_position_keys(ix, t_chr, t_nk, t_nv, pos - rem, L, a.strand, &h)) {  // searcher.hpp:504-539
+                payload = h.pos0;
+                chr_id = h.chr_id;
+                meta |= R_NH | (h.is_rc ? R_RC : 0u);
+                fits = chr_id <= a.ring_chr_max && payload <= kPosMask;
+              }
+            }
+          }
+          if (fits) {  // (a result no record holds stays pending: the general kernels own the wide path)
+            e1 = payload | ((uint64_t)chr_id << kPosBits) | ((uint64_t)meta << 56);
+            pending = false;
+          }
+        }
+      }
+    }
+    if (pending && !missed) ++other_n;
+    // records leave as whole lines: a pending read's slot is written too (zeros) and overwritten by k_scatter_pending
+    if (valid) reinterpret_cast<uint4*>(a.out)[r] = make_uint4(0, 0, (uint32_t)e1, (uint32_t)(e1 >> 32));
+    const uint64_t pm = __ballot(pending);
+    if (pm) {
+      if (pending) s_pend[n_buf + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+      n_buf += (uint32_t)__popcll(pm);
+      if (n_buf > kSettleBuf - 64) flush_pending();
+    }
+    valid = nvalid;
+    rec = nrec;
+    L = nL;
+  }
+  if (n_buf) flush_pending();
+  for (int d = 32; d > 0; d >>= 1) {
+    looked += __shfl_xor(looked, d);
+    found_n += __shfl_xor(found_n, d);
+    other_n += __shfl_xor(other_n, d);
+  }
+  if (lane == 0 && looked) {
+    atomicAdd(a.index_accesses, (unsigned long long)looked);
+    atomicAdd(a.hash_stats, (unsigned long long)looked);
+    atomicAdd(a.hash_stats + 1, (unsigned long long)found_n);
+  }
+  if (lane == 0 && other_n) atomicAdd(a.pending_other, (unsigned long long)other_n);
+}
+
+// the pending reads as a dense batch: record and length of read list[i] at slot i
+__global__ __launch_bounds__(256) void k_gather_pending(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ lens,
+                                                        const uint32_t* __restrict__ list, uint64_t n_pending,
+                                                        uint32_t* __restrict__ packed2, uint32_t* __restrict__ lens2) {
+  const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pending) return;
+  const uint32_t r = list[i];
+  reinterpret_cast<uint4*>(packed2)[i] = reinterpret_cast<const uint4*>(packed)[r];
+  lens2[i] = lens[r];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_pending(const sbwt_compact_result* __restrict__ from, const uint32_t* __restrict__ list,
+                                                         uint64_t n_pending, sbwt_compact_result* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pending) return;
+  reinterpret_cast<uint4*>(out)[list[i]] = reinterpret_cast<const uint4*>(from)[i];
+}
+
+}  // namespace sbwt

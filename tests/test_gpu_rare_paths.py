@@ -155,8 +155,9 @@ def test_results_that_bypass_the_ring(sb, oracle, golden_indexes, golden_dir, mo
 
 # ---- prefix-table sizing under a budget ---------------------------------------------------------
 GB = 1 << 30
-HEADROOM = 24 * GB
-HASH20 = (1 << 25) * 32          # order-20 hash table of an index below 2^27 suffixes: 2^25 buckets of 32 bytes
+HEADROOM = 16 * GB                # device_index.hip: kKmerHeadroom
+HASH8 = (1 << 25) * 32           # order-20 hash table of an index below 2^27 suffixes: 2^25 buckets of four 8-byte slots
+HASH16 = (1 << 25) * 64          # ... of four 16-byte slots (with the text behind the prefix)
 DIRECT13 = (4 ** 13) * 8
 
 
@@ -214,40 +215,49 @@ def same_as(sb_, ix, reads, want):
     np.testing.assert_array_equal(res["nh"], nh)
     idx = lambda f, k: (np.repeat(f, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))).astype(np.int64)  # noqa: E731
     assert np.array_equal(hits[idx(res["first_hit"], nh)], ohits[idx(first, nh)])
+    ctx = sb_.Context(ix, len(reads))
+    rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=sb_.MAP_HITS_ONLY)
+    ctx.close()
+    res2, hits2 = sb_.compact_expand(rec, lists, wide)
+    np.testing.assert_array_equal(res2["nh"], nh)
+    assert np.array_equal(hits2[idx(res2["first_hit"], nh)], ohits[idx(first, nh)])
     return lines
+
+
+def orders(ix):
+    info = ix.info()
+    return (info.kmer_order, info.hash_order, info.hash_text)
 
 
 def test_unconstrained_choice(budget_world):
     sb_, build, ix0, reads, want = budget_world
-    info = ix0.info()
-    assert (info.kmer_order, info.hash_order) == (13, 20)
+    assert orders(ix0) == (13, 20, 1)
     same_as(sb_, ix0, reads, want)
 
 
 @pytest.mark.parametrize("free_bytes,expect", [
-    (HEADROOM + HASH20 + DIRECT13 + 4096, (13, 20)),    # both tables just fit
-    (HEADROOM + HASH20 + 4096, (12, 20)),               # the hash table fits, no direct table beside it
-    (HEADROOM + DIRECT13 + 4096, (13, 0)),              # no room for the hash table: direct table alone
-    (1 * GB, (12, 0)),                                  # nothing fits: c_functions and rank queries only
+    (HEADROOM + HASH16 + DIRECT13 + 4096, (13, 20, 1)),   # everything just fits
+    (HEADROOM + HASH16 + 4096, (12, 20, 1)),              # the hash table with text fits, no direct table beside it
+    (HEADROOM + HASH8 + DIRECT13 + 4096, (13, 20, 0)),    # 8-byte slots and the direct table
+    (HEADROOM + DIRECT13 + 4096, (13, 0, 0)),             # no room for a hash table: direct table alone
+    (1 * GB, (12, 0, 0)),                                 # nothing fits: c_functions and rank queries only
 ])
 def test_table_sizes_follow_the_budget(budget_world, monkeypatch, free_bytes, expect):
     sb_, build, ix0, reads, want = budget_world
     monkeypatch.setenv("SBWT_DEBUG_FREE_BYTES", str(free_bytes))
     ix, _ = build()
-    info = ix.info()
-    assert (info.kmer_order, info.hash_order) == expect
+    assert orders(ix) == expect
     lines = same_as(sb_, ix, reads, want)
-    if expect == (12, 0):
+    if expect == (12, 0, 0):
         assert lines > 3 * len(reads)                   # no memoised prefix: c_functions, rank steps, then the text
     ix.close()
 
 
-@pytest.mark.parametrize("fail,expect", [("hash", (13, 0)), ("kmer", (12, 20)), ("both", (12, 0))])
+@pytest.mark.parametrize("fail,expect", [("hash", (13, 0, 0)), ("kmer", (12, 20, 1)), ("both", (12, 0, 0))])
 def test_table_allocation_failure_is_survived(budget_world, monkeypatch, fail, expect):
     sb_, build, ix0, reads, want = budget_world
     monkeypatch.setenv("SBWT_DEBUG_FAIL_TABLE_ALLOC", fail)
     ix, _ = build()
-    info = ix.info()
-    assert (info.kmer_order, info.hash_order) == expect
+    assert orders(ix) == expect
     same_as(sb_, ix, reads, want)
     ix.close()

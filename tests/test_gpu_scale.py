@@ -123,3 +123,36 @@ def test_small_rna_multi_hit_reads(world):
     assert nh.max() >= 999 and (res["flags"] & sb.RF_SUPPRESSED).any()
     for limit, strand in ((5, 2), (1000, 0), (1000, 1), (-1, 2)):
         check(sb, ix, oix, reads[-400:], limit=limit, strand=strand)
+
+
+def test_hits_only_fast_pass_settles_most_reads(world):
+    """SBWT_MAP_HITS_ONLY on an index with text in its hash slots: k_settle answers the reads its buckets settle with
+    one access each and leaves the rest to the general kernels; hits, NH and flags equal the oracle's for every
+    read, and SA intervals are reported only by the reads that took the general path"""
+    sb, ix, oix, codes, fam, rng = world
+    assert ix.info().hash_order == 20
+    reads = sample_reads(rng, codes, 30000, [32, 36, 50, 51, 52, 53, 60])
+    for f in fam[:8]:
+        reads.append(bytes(b"ACGT"[c] for c in f))
+    packed, lens = sb.pack_reads(reads)
+    ctx = sb.Context(ix, len(reads))
+    lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+    for limit, strand in ((1000, 2), (0, 2), (1000, 0), (1000, 1)):
+        if (limit, strand) != (1000, 2):
+            lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand, nthreads=8)
+        rec, lists, wide = ctx.map_batch_compact(packed, lens, limit=limit, strand=strand, mode=sb.MAP_HITS_ONLY)
+        meta = (rec["w1"] >> np.uint64(56)).astype(np.uint32)
+        no_sa = (meta & sb.CR_NO_SA) != 0
+        L = lens
+        assert no_sa[(L > 20) & (L <= 52)].mean() > 0.8 and not no_sa[L > 52].any()
+        res, hits = sb.compact_expand(rec, lists, wide)
+        np.testing.assert_array_equal(res["nh"], nh)
+        np.testing.assert_array_equal(res["sa_lo"][~no_sa], lo[~no_sa])
+        np.testing.assert_array_equal(res["sa_hi"][~no_sa], hi[~no_sa])
+        k = np.maximum(nh, 0)
+        gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+        oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+        assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+        t = ctx.last_timing_ex()
+        assert t[3] > 0 and t[4] > 0                      # both passes ran
+    ctx.close()
