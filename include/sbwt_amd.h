@@ -163,6 +163,12 @@ int sbwt_host_tables_save(const sbwt_host_tables *t, const char *table_path);
 int sbwt_ctx_create(const sbwt_index *ix, uint64_t max_reads, sbwt_ctx **out);
 void sbwt_ctx_free(sbwt_ctx *ctx);
 
+/* How reads are shared out over devices or ranks: share k of `parts` is the contiguous range [*begin, *end) of
+ * n_items; the ranges tile [0, n_items) in order of k and their sizes differ by at most one.  Used by
+ * sbwt_map_fastq_multi for every batch and by the one-process-per-GPU driver (bench.py, sbwt_amd/shard.py) for the
+ * whole input: shares in order of k = input order (job_distributer.hpp:53-67 hands out groups in reading order). */
+int sbwt_shard_range(uint64_t n_items, uint32_t parts, uint32_t k, uint64_t *begin, uint64_t *end);
+
 /* Read encoding.  Base j of read r is the 2-bit code (A=0,C=1,G=2,T=3) at bits [2*(j%16), 2*(j%16)+1]
  * of 32-bit word  r*words_per_read + j/16 ; words_per_read is a multiple of 4 (16-byte records).
  * sbwt_pack_reads packs ASCII reads (concatenated, offsets[n_reads+1]) and reports the first read the
@@ -265,6 +271,14 @@ void *sbwt_ctx_stream(const sbwt_ctx *ctx);
  * n_threads = host threads for parsing / SAM formatting (`sbwt map -n`). */
 int sbwt_map_fastq(const sbwt_index *ix, const char *fastq_path, const char *sam_path, int limit, int strand,
                    int n_threads, uint64_t stats[5]);
+/* The same over several GPUs: ixs[0..n_ix) are replicas of ONE index, each loaded on its own device
+ * (sbwt_index_load(prefix, device, ..) once per device).  Every batch of reads is cut into n_ix contiguous shares,
+ * one per device, mapped at the same time by one host thread and ctx per device; there is no exchange between the
+ * devices, and the SAM records leave in input order whatever the number of devices.  Upstream's only parallel
+ * driver is the thread pool of Job_distributer<M_T>::distribute_jobs (job_distributer.hpp:37-90, sized by
+ * GlobalPool.ChangePoolSize, main.cpp:231); this is its multi-device analogue. */
+int sbwt_map_fastq_multi(const sbwt_index *const *ixs, int n_ix, const char *fastq_path, const char *sam_path, int limit,
+                         int strand, int n_threads, uint64_t stats[5]);
 
 #ifdef __cplusplus
 }

@@ -7,5 +7,5 @@ is missing.
 from .api import (  # noqa: F401
     SbwtError, Index, Context, Hit, ReadResult, lib, lib_path, pack_reads, words_per_read,
     device_count, build_index, build_index_device, host_tables_free, host_tables_save, HostTables, RF_SUPPRESSED, RF_TRUNCATED,
-    compact_expand, MAP_HITS_ONLY, CR_NO_SA, CR_WIDE, CR_UNIQUE, CR_MULTI, COMPACT_DTYPE, WIDE_DTYPE,
+    compact_expand, map_fastq_multi, MAP_HITS_ONLY, CR_NO_SA, CR_WIDE, CR_UNIQUE, CR_MULTI, COMPACT_DTYPE, WIDE_DTYPE,
 )

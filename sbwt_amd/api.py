@@ -106,6 +106,7 @@ def lib():
     L.sbwt_ctx_create.argtypes = [vp, u64, p(vp)]
     L.sbwt_ctx_free.argtypes = [vp]
     L.sbwt_ctx_free.restype = None
+    L.sbwt_shard_range.argtypes = [u64, u32, u32, p(u64), p(u64)]
     L.sbwt_words_per_read.argtypes = [u32]
     L.sbwt_words_per_read.restype = u32
     L.sbwt_pack_reads.argtypes = [vp, vp, u64, u32, vp, vp, p(u64)]
@@ -126,6 +127,7 @@ def lib():
     L.sbwt_ctx_stream.argtypes = [vp]
     L.sbwt_ctx_stream.restype = vp
     L.sbwt_map_fastq.argtypes = [vp, C.c_char_p, C.c_char_p, i32, i32, i32, p(u64 * 5)]
+    L.sbwt_map_fastq_multi.argtypes = [p(vp), i32, C.c_char_p, C.c_char_p, i32, i32, i32, p(u64 * 5)]
     _lib = L
     return L
 
@@ -165,6 +167,13 @@ class PinnedBuffer:
             self.close()
         except Exception:
             pass
+
+
+def shard_range(n_items, parts, k):
+    """sbwt_shard_range: contiguous share k of `parts` of n_items"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().sbwt_shard_range(int(n_items), int(parts), int(k), C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def words_per_read(max_len):
@@ -222,6 +231,15 @@ def compact_expand(rec, list_hits, wide):
                                      list_hits.ctypes.data if list_hits.size else None, list_hits.size, res.ctypes.data,
                                      hits.ctypes.data))
     return res, hits
+
+
+def map_fastq_multi(indexes, fastq, sam, limit=1000, strand=2, n_threads=1):
+    """sbwt_map_fastq_multi: `indexes` are replicas of one index, one per device"""
+    arr = (C.c_void_p * len(indexes))(*[ix._h for ix in indexes])
+    st = (C.c_uint64 * 5)()
+    _check(lib().sbwt_map_fastq_multi(arr, len(indexes), os.fsencode(fastq), os.fsencode(sam), limit, strand, n_threads,
+                                      C.byref(st)))
+    return list(st)
 
 
 def host_tables_free(t):

@@ -212,6 +212,17 @@ extern "C" const char* sbwt_index_chr_name(const sbwt_index* ix, uint64_t i) {
   return ix->chr.names[i].c_str();
 }
 
+extern "C" int sbwt_shard_range(uint64_t n_items, uint32_t parts, uint32_t k, uint64_t* begin, uint64_t* end) {
+  if (parts == 0 || k >= parts || !begin || !end) {
+    set_error("sbwt_shard_range: bad argument");
+    return SBWT_ERR_ARG;
+  }
+  const uint64_t base = n_items / parts, extra = n_items % parts;
+  *begin = (uint64_t)k * base + ((uint64_t)k < extra ? (uint64_t)k : extra);
+  *end = *begin + base + ((uint64_t)k < extra ? 1 : 0);
+  return SBWT_OK;
+}
+
 extern "C" uint32_t sbwt_words_per_read(uint32_t max_len) {
   uint32_t w = (max_len + 15) / 16;
   w = (w + 3) & ~3u;

@@ -578,10 +578,14 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
       const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
       const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | (vv & ((1ull << tag_bits) - 1ull));
       const uint32_t stride = with_text ? 2u : 1u;  // words per slot
-      unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + b * kHashSlots * stride;
       outcome = 2;  // bucket full: this K-mer stays with the fallback path
-      for (uint32_t s = 0; s < kHashSlots; ++s)
-        if (atomicCAS(&bk[s * stride], ~0ull, (unsigned long long)slot) == ~0ull) {
+      // With text, a prefix that finds its bucket full goes to the other bucket of the same 128-byte line (b ^ 1): the
+      // values of two neighbouring buckets differ by less than 2^tag_bits, so the tag still tells them all apart,
+      // and k_settle looks there only when the first bucket has no free slot.
+      const uint32_t tries = (with_text && (n_buckets & 1ull) == 0) ? 2u * kHashSlots : kHashSlots;
+      for (uint32_t s = 0; s < tries; ++s) {
+        unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + ((s < kHashSlots ? b : (b ^ 1ull)) * kHashSlots + (s & (kHashSlots - 1))) * stride;
+        if (atomicCAS(&bk[0], ~0ull, (unsigned long long)slot) == ~0ull) {
           outcome = 1;
           if (with_text) {
             // what the read's bases K .. K+31 are compared with: textrc[m - p ..) (search_machine.h, S_CMP: x0 = n - 1 - p)
@@ -589,10 +593,11 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
             const uint32_t* ty = ix.textrc + (x1 >> 4);
             const uint32_t sh1 = 2u * (uint32_t)(x1 & 15);
             const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
-            bk[s * stride + 1] = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
+            bk[1] = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
           }
           break;
         }
+      }
     }
   }
   // statistics: one pair of atomics per wave
@@ -766,6 +771,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     uint64_t slot_bytes = 8;
     if (H) {
       n_buckets = (raw.n * 8 / 5 + kHashSlots - 1) / kHashSlots;  // 1.6 slots per suffix
+      n_buckets += n_buckets & 1ull;                              // whole 128-byte lines of two buckets (hash_buddy)
       // a tag of at most 16 bits must tell the values of one bucket apart: 2^(tag_bits - 1) >= 4^H / n_buckets
       if (2 * H > 15 && n_buckets < (1ull << (2 * H - 15))) n_buckets = 1ull << (2 * H - 15);
       tag_bits = 1;
@@ -802,6 +808,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     d.hash_buckets = 0;
     d.hash_tag_bits = 0;
     d.hash_text = 0;
+    d.hash_buddy = 0;
     // both prefix tables are optional: an allocation that fails (fragmented or shared device memory) leaves the
     // index without that table, slower and with the same results
     uint64_t* htab = nullptr;
@@ -825,6 +832,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       d.hash_buckets = n_buckets;
       d.hash_tag_bits = tag_bits;
       d.hash_text = with_text ? 1u : 0u;
+      d.hash_buddy = (with_text && (n_buckets & 1ull) == 0) ? 1u : 0u;
     }
     d.kmer_order = K;
     d.kmer_tab = nullptr;

@@ -103,6 +103,7 @@ struct DeviceIndex {
   // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised; kKmerLocated form below)
   const uint64_t* kmer_tab; uint32_t kmer_order;  // kmer_order = 12: no table
   const uint64_t* hash_tab; uint64_t hash_buckets; uint32_t hash_order; uint32_t hash_tag_bits;  // hash_order = 0: none
+  uint32_t hash_buddy;      // 1 (with hash_text): a prefix whose bucket was full may sit in bucket ^ 1, the other half of its 128-byte line
   uint32_t hash_text;       // 1: 16-byte slots, the second word = the 32 bases textrc[n-1-pos .. n-1-pos+32) a read's next bases must equal
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)

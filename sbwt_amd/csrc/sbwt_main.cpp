@@ -7,6 +7,7 @@
 
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/sbwt_amd.h"
 
@@ -21,7 +22,7 @@ static bool index_intact(const std::string& prefix) {  // main.cpp:34-47
 static const char* kUsage =
     "\n+----+\n|sBWT|  (MI355X build)\n+----+\n\nUsage:\n\n 1. building index of the genome\n>\tsbwt build -i genome.fa -p prefix "
     "[-l 256] [-s 64] [-f]\n\n 2. mapping fastq to the index\n>\tsbwt map -i reads.fq -p prefix [-o stdout] [-n 1] [-m 1000] "
-    "[-s 2]\n\n";
+    "[-s 2] [-g 1]\n\t(-g: GPUs to map on, 0 = all; the index is loaded on each, the reads are shared out)\n\n";
 
 struct Opt {
   const char *s, *l;
@@ -64,7 +65,7 @@ static int cmd_build(int argc, char** argv) {
 
 static int cmd_map(int argc, char** argv) {
   std::string fastq, prefix, sam = "stdout";
-  int nthread = 1, limit = 1000, strand = 2;
+  int nthread = 1, limit = 1000, strand = 2, gpus = 1;
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : nullptr;
@@ -76,6 +77,7 @@ static int cmd_map(int argc, char** argv) {
     else if (is_opt(a, "-n", "--thread")) nthread = atoi(v);
     else if (is_opt(a, "-m", "--multiple")) limit = atoi(v);
     else if (is_opt(a, "-s", "--strand")) strand = atoi(v);
+    else if (is_opt(a, "-g", "--gpus")) gpus = atoi(v);
     else { fprintf(stderr, "Error: unrecognised option %s\n%s", a, kUsage); return 1; }
     ++i;
   }
@@ -97,12 +99,31 @@ static int cmd_map(int argc, char** argv) {
   }
   fprintf(stderr, "Parameters fastq: %s\nParameters prefix: %s\nParameters output: %s\nParameters thread: %d\nParameters multiple: %d\nParameters strand: %d\n",
           fastq.c_str(), prefix.c_str(), sam.c_str(), nthread, limit, strand);
-  sbwt_index* ix = nullptr;
-  int rc = sbwt_index_load(prefix.c_str(), 0, &ix);
-  if (rc != SBWT_OK) { fprintf(stderr, "Error: %s\n", sbwt_last_error()); return 2; }
+  int n_dev = 0;
+  if (sbwt_device_count(&n_dev) != SBWT_OK) { fprintf(stderr, "Error: %s\n", sbwt_last_error()); return 2; }
+  if (gpus <= 0 || gpus > n_dev) gpus = n_dev;
+  // one replica of the index per device, loaded side by side
+  std::vector<sbwt_index*> ixs((size_t)gpus, nullptr);
+  std::vector<int> rcs((size_t)gpus, SBWT_OK);
+  std::vector<std::string> errs((size_t)gpus);
+  {
+    std::vector<std::thread> th;
+    for (int d = 0; d < gpus; ++d)
+      th.emplace_back([&, d] {
+        rcs[(size_t)d] = sbwt_index_load(prefix.c_str(), d, &ixs[(size_t)d]);
+        if (rcs[(size_t)d] != SBWT_OK) errs[(size_t)d] = sbwt_last_error();
+      });
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < gpus; ++d)
+    if (rcs[(size_t)d] != SBWT_OK) {
+      fprintf(stderr, "Error: %s\n", errs[(size_t)d].c_str());
+      for (auto* x : ixs) sbwt_index_free(x);
+      return 2;
+    }
   uint64_t st[5] = {0, 0, 0, 0, 0};
-  rc = sbwt_map_fastq(ix, fastq.c_str(), sam.c_str(), limit, strand, nthread, st);
-  sbwt_index_free(ix);
+  int rc = sbwt_map_fastq_multi(ixs.data(), gpus, fastq.c_str(), sam.c_str(), limit, strand, nthread, st);
+  for (auto* x : ixs) sbwt_index_free(x);
   if (rc != SBWT_OK) {
     fprintf(stderr, "Error: %s\n", sbwt_last_error());
     // upstream dies in std::terminate on such reads (SIGABRT); keep the same exit status

@@ -127,27 +127,40 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
     if (look) ++looked;
-    // round k: the quad loads the bucket of its lane k, lane `sub` the slot `sub`
-    uint4 piece[4];
-    uint32_t want[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t b_lo = quad_bcast((uint32_t)bucket, k), b_hi = quad_bcast((uint32_t)(bucket >> 32), k);
-      want[k] = quad_bcast(look ? 1u : 0u, k);
-      piece[k] = make_uint4(~0u, ~0u, 0, 0);
-      if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
-    }
+    // round k: the quad loads the bucket of its lane k, lane `sub` the slot `sub`.  A prefix that found its bucket
+    // full when the table was built sits in the other bucket of the same 128-byte line (device_index.hip): a
+    // second pass looks there for the reads whose first bucket has the tag nowhere and no free slot.
     uint64_t slot = ~0ull, text = 0;
+    bool again = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool go = pass == 0 ? look : again;
+      if (!__any(go)) break;
+      const uint64_t bk = pass == 0 ? bucket : (bucket ^ 1ull);
+      uint4 piece[4];
+      uint32_t want[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t tag_k = quad_bcast(tag, k);
-      const bool hit = want[k] && ((piece[k].x ^ tag_k) & tmask) == 0 && piece[k].y != 0xFFFFFFFFu;
-      // at most one slot of a bucket carries the tag: OR the (masked) slot over the quad
-      uint32_t v0 = hit ? piece[k].x : 0u, v1 = hit ? piece[k].y : 0u, v2 = hit ? piece[k].z : 0u, v3 = hit ? piece[k].w : 0u;
-      uint32_t any = hit ? 1u : 0u;
-      v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); v2 |= quad_swap1(v2); v3 |= quad_swap1(v3); any |= quad_swap1(any);
-      v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
-      if (sub == (uint32_t)k && any) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t b_lo = quad_bcast((uint32_t)bk, k), b_hi = quad_bcast((uint32_t)(bk >> 32), k);
+        want[k] = quad_bcast(go ? 1u : 0u, k);
+        piece[k] = make_uint4(~0u, ~0u, 0, 0);
+        if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t tag_k = quad_bcast(tag, k);
+        const bool used = piece[k].y != 0xFFFFFFFFu;
+        const bool hit = want[k] && used && ((piece[k].x ^ tag_k) & tmask) == 0;
+        // at most one slot of the two buckets carries the tag: OR the (masked) slot over the quad
+        uint32_t v0 = hit ? piece[k].x : 0u, v1 = hit ? piece[k].y : 0u, v2 = hit ? piece[k].z : 0u, v3 = hit ? piece[k].w : 0u;
+        uint32_t any = (hit ? 1u : 0u) | (used ? 0u : 2u);  // bit 0: found; bit 1: a free slot (nothing was ever displaced)
+        v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); v2 |= quad_swap1(v2); v3 |= quad_swap1(v3); any |= quad_swap1(any);
+        v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
+        if (sub == (uint32_t)k && go) {
+          if (any & 1u) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
+          again = pass == 0 && any == 0u && ix.hash_buddy;
+        }
+      }
     }
     bool missed = false;  // looked up and not in the table: the general kernels need not look again
     if (look) {

@@ -11,12 +11,12 @@ import time
 
 
 def shard_range(n_items, rank, world):
-    """Contiguous range [a, b) of rank `rank`; ranges tile [0, n_items) in rank order, sizes differ by <= 1."""
+    """Contiguous range [a, b) of rank `rank`; ranges tile [0, n_items) in rank order, sizes differ by <= 1.
+    The arithmetic is the library's own (sbwt_shard_range, the one sbwt_map_fastq_multi cuts its batches with)."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
-    base, extra = divmod(int(n_items), world)
-    a = rank * base + min(rank, extra)
-    return a, a + base + (1 if rank < extra else 0)
+    from . import api
+    return api.shard_range(n_items, world, rank)
 
 
 def barrier(dist, sync=None):
