@@ -231,7 +231,7 @@ def spawn_ranks(n, argv):
     import subprocess
     import torch
     have = torch.cuda.device_count()           # counts devices without initialising the GPU (see the task's notes)
-    if have < n:
+    if have < n and not os.environ.get("BENCH_SHARE_DEVICE"):
         raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s)" % (n, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -244,7 +244,8 @@ def spawn_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    for ln in out.decode().splitlines():     # rank 0's JSON line; anything a backend printed beside it goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     if any(codes):
         raise SystemExit("bench.py: rank exit codes %s" % codes)
@@ -374,12 +375,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the library has no CPU fallback")
+    if os.environ.get("BENCH_SHARE_DEVICE"):   # rehearsal of the N > 1 path on a one-GPU box: all ranks on device 0, gloo
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("BENCH_SHARE_DEVICE"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     t0 = time.time()
     L = args.read_len
@@ -512,11 +518,21 @@ def main():
     # the kernel itself: search-prefix entry, two-base blocks, memoised locate, text comparison, final row)
     # + the streamed bytes (read record + length in, result + hit out).
     stats = ctx.last_stats_ex()
-    accesses = int(stats[0])
+    settle_ms = float(np.mean([k[3] for k in kernel_ms]))
+    pending_ms = float(np.mean([k[4] for k in kernel_ms]))
     out_bytes = 16 if compact else 48     # per read: one 16-byte record, or a 32-byte record + the 16-byte hit slot
-    streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(n_hits) * 16
+    if settle_ms > 0:
+        # hits layout: the dominant kernel is k_settle -- one bucket (one line) per looked-up read, records in, records out
+        dom_kernel, dom_ms = "k_settle", settle_ms
+        accesses = int(stats[6])
+        streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(stats[7]) * 4
+    else:
+        dom_kernel, dom_ms = "k_search_sm", search_ms
+        accesses = int(stats[0])
+        streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(n_hits) * 16
     algo_bytes = 128 * accesses + streamed
-    achieved = algo_bytes / (search_ms * 1e-3) / 1e9
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+    all_accesses = int(stats[0])
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
     # the random-access roofline of THIS device, measured in this process over the index's own largest table
     probe = {}
@@ -524,27 +540,36 @@ def main():
         rate, pbytes = ix.probe_random_access(chains_per_lane=cpl, chain_len=64, workgroups_per_cu=8)
         probe["%d_chains_per_lane" % cpl] = round(rate / 1e9, 2)
     gather_peak = max(probe.values())
-    lines_per_s = accesses / (search_ms * 1e-3) / 1e9
+    lines_per_s = accesses / (dom_ms * 1e-3) / 1e9
     stored = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes of an earlier run (another box): context only
+    tpath = os.path.join(ROOT, "profiles", "r2", "traffic_%s.json" % args.layout)   # PMC passes of an earlier run: context only
     if os.path.exists(tpath):
         t = json.load(open(tpath))
         if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9 and plain \
-                and not args.rank_path:
-            stored = {"source": "profiles/traffic.json (rocprofv3 --pmc passes of an earlier run on another box; NOT measured in this run)",
+                and not args.rank_path and t.get("kernel") == dom_kernel:
+            stored = {"source": "profiles/r2/traffic_%s.json (rocprofv3 --pmc passes of the same command on another box of this "
+                                "pool; NOT measured in this run)" % args.layout,
                       "traffic_GB_per_launch": t.get("traffic_GB_per_launch"),
-                      "hbm_requests_per_launch": (t.get("TCC_EA0_RDREQ", 0) + t.get("TCC_EA0_WRREQ", 0)) or None}
-    roofline = {"bound": "hbm", "kernel": "k_search_sm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
-                "launch_ms": round(search_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
+                      "hbm_requests_per_launch": t.get("hbm_requests_per_launch")}
+    roofline = {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": stored["traffic_GB_per_launch"] if stored else None,
+                "traffic_source": stored["source"] if stored else None,
+                "launch_ms": round(dom_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
+                "algorithmic_bytes": "128 B per index line the kernel reads (a random access moves one 128-byte line of HBM whatever "
+                                     "part of it is used: the probe below runs at the same rate for 16 .. 128-byte granules) + streamed "
+                                     "bytes (record and length in, result out)",
                 "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
                 "index_lines_per_s_G": round(lines_per_s, 2),
                 "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
                                     "table_GB": round(pbytes / 1e9, 1), "by_chains_per_lane": probe, "peak": gather_peak,
                                     "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3)},
+                "whole_step": {"device_ms": round(float(np.mean([k[0] for k in kernel_ms])), 3),
+                               "index_lines_per_read": round(all_accesses / n_reads, 3),
+                               "k_settle_ms": round(settle_ms, 3), "pending_pass_ms": round(pending_ms, 3),
+                               "reads_left_pending": int(stats[7])},
                 "hash_lookups_per_read": round(stats[4] / n_reads, 4), "hash_hit_rate": round(stats[5] / stats[4], 4) if stats[4] else None,
                 "stored_pmc": stored,
-                "survey_formula_GBps": round(survey_per_read * n_reads / (search_ms * 1e-3) / 1e9, 1)}
+                "survey_formula_GBps": round(survey_per_read * n_reads / (dom_ms * 1e-3) / 1e9, 1)}
 
     cpu = None
     parity = None

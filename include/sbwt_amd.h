@@ -252,8 +252,9 @@ int sbwt_ctx_last_timing_ex(const sbwt_ctx *ctx, float *ms, uint32_t n);
  * the multi-hit locate, [2] hit slots in use, [3] multi-hit reads that needed the depth-first walk.  No upstream counterpart: measurement only. */
 int sbwt_ctx_last_stats(const sbwt_ctx *ctx, uint64_t stats[4]);
 /* The same and more: the first n counters of [0..3] as above, [4] hash_tab lookups the search kernel made, [5] those
- * that found their search prefix in it (the hash hit rate of a workload); counters beyond the ones the
- * library knows read 0. */
+ * that found their search prefix in it (the hash hit rate of a workload), [6] index lines the hits-only
+ * fast pass (k_settle) read, [7] reads it left to the general kernels; counters beyond the ones the library knows
+ * read 0. */
 int sbwt_ctx_last_stats_ex(const sbwt_ctx *ctx, uint64_t *stats, uint32_t n);
 /* The random-access roofline of the device, measured over the index's own largest table ("a random
  * granule gather microbenchmark over a table of the same footprint on the same GPU"): every lane walks

@@ -160,7 +160,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 6;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 8;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -186,7 +186,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -516,7 +516,10 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const bool settle = (mode & SBWT_MAP_HITS_ONLY) && d.hash_text && d.hash_order && words_per_read == 4 && c->d_pend_list &&
                       !getenv("SBWT_NO_SETTLE");
   if (!settle) {
-    if (!accumulate) c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
+    if (!accumulate) {
+      c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
+      c->last_stats[6] = c->last_stats[7] = 0;
+    }
     return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, multi_base,
                     multi_used, wide_used, accumulate, c->last_ms, c->last_stats);
   }
@@ -563,7 +566,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     SBWT_LAUNCHED();
     const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, 4, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
@@ -574,13 +577,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5]};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }

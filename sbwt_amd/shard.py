@@ -39,7 +39,8 @@ def timed_steps(step, steps, warmup, dist=None, sync=None, device=None):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        on_cpu = device is None or dist.get_backend() == "gloo"
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_cpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
