@@ -103,7 +103,7 @@ def plant_repeats(torch, dev, codes, g, seed, n_families=2000, max_copies=5000):
 
 def plant_repeat_families(torch, dev, codes, g, seed, frac=0.40):
     """--genome repeats: `frac` of the bases are overwritten by copies of repeat families, every copy carrying its own
-    substitutions (interspersed-repeat-like: 150 families, consensus 300 .. 6,000 bp, divergence 0 .. 15 % per
+    substitutions (interspersed-repeat-like: 150 families, consensus 300 .. 6,000 bp, divergence 1 .. 15 % per
     family), plus 40 exact duplications of 2 .. 20 kb in 2 .. 6 copies (ties beyond sort_len for the suffix order).
     Returns the fraction of bases covered."""
     gen = torch.Generator(device=dev)
@@ -112,7 +112,7 @@ def plant_repeat_families(torch, dev, codes, g, seed, frac=0.40):
     covered = 0
     fams = []
     for f in range(150):
-        fams.append((int(rng.integers(300, 6001)), float(rng.choice([0.0, 0.02, 0.05, 0.10, 0.15])), 1.0))
+        fams.append((int(rng.integers(300, 6001)), float(rng.choice([0.01, 0.02, 0.05, 0.10, 0.15])), 1.0))
     for f in range(40):
         fams.append((int(rng.integers(2000, 20001)), 0.0, 0.0))
     budget = int(g * frac)
@@ -430,13 +430,15 @@ def main():
     compact = args.layout != "plain"
     mode = sbwt_amd.MAP_HITS_ONLY if args.layout == "hits" else 0
     wide_cap = 1 << 16
+    free_b, _ = torch.cuda.mem_get_info()
+    list_cap = int(min(80 * n_reads, max(1 << 20, (free_b - (6 << 30)) // 16)))       # room for the lists of multi-hit reads
     if compact:
         results = torch.empty(n_reads * 16, dtype=torch.uint8, device=dev)            # sbwt_compact_result[n_reads]
-        hits_cap = (1 << 20) if not many_hits else int(min(80 * n_reads, 6e9))        # lists of multi-hit reads only
+        hits_cap = (1 << 20) if not many_hits else list_cap                           # lists of multi-hit reads only
         wide = torch.empty(wide_cap * 48, dtype=torch.uint8, device=dev)
     else:
         results = torch.empty(n_reads * 32, dtype=torch.uint8, device=dev)            # sbwt_read_result[n_reads]
-        hits_cap = n_reads + (1 << 20) if not many_hits else int(min(80 * n_reads, 6e9))
+        hits_cap = n_reads + (1 << 20) if not many_hits else n_reads + list_cap
     hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
 
     def step():
@@ -691,7 +693,8 @@ def main():
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": config1,
         "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "list_hits": int(n_hits), "wide_records": n_wide_rec,
-                   "reads_without_sa_interval": n_no_sa,
+                   "reads_without_sa_interval": n_no_sa, "reads_to_multi_hit_locate": int(stats[1]),
+                   "reads_to_depth_first_locate": int(stats[3]),
                    "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
                    "k_settle_ms": round(float(np.mean([k[3] for k in kernel_ms])), 3),
                    "pending_pass_ms": round(float(np.mean([k[4] for k in kernel_ms])), 3),

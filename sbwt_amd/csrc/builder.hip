@@ -9,8 +9,10 @@
 // 27 base-5 digits ('$'/past-the-end = 0, A..T = 1..4), so '$' sorts first with no special case and a key
 // that contains a 0 digit is unique.  Suffixes are partitioned by their leading digits, each partition is
 // radix-sorted (rocPRIM; this is offline plumbing, not the hot path), and groups of equal keys are refined
-// 27 bases at a time until they are resolved or 270 >= sort_len bases deep -- a full suffix order
-// wherever the text allows one, which is a valid sort_len-order for every sort_len <= 270.
+// 27 bases at a time until they are resolved or 1080 >= sort_len bases deep -- a full suffix order
+// wherever the text allows one, which is a valid sort_len-order for every sort_len <= 1080.  (Deeper than upstream's
+// default 256 on purpose: suffixes left tied sit in position order, which is not LF-consistent where a tie ends, and
+// reads whose rows fall there take the slow depth-first locate; 1080 leaves only long exact repeats tied.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,7 +31,7 @@ using std::memset;
 namespace sbwt {
 
 constexpr int kDigits = 27;       // 5^27 < 2^63
-constexpr int kMaxDepth = 270;    // refinement stops here (>= default sort_len 256)
+constexpr int kMaxDepth = 1080;   // refinement stops here (>= default sort_len 256; deep enough to order everything but long exact repeats)
 constexpr uint64_t kMaxPartition = 1ull << 29;
 
 struct Text {
@@ -897,7 +899,7 @@ extern "C" int sbwt_build_index(const char* fasta_path, const char* prefix_in, u
                                 int device) {
   if (!fasta_path || !prefix_in) return SBWT_ERR_ARG;
   if (sort_len > (uint64_t)kMaxDepth) {
-    set_error("sort_len above 270 is not supported");
+    set_error("sort_len above 1080 is not supported");
     return SBWT_ERR_ARG;
   }
   std::string prefix(prefix_in);

@@ -7,6 +7,10 @@
 // The emission order is therefore: rows sorted by that prepended string in pre-order (a string before its
 // extensions, A<C<G<T), rows with the same string in row order.  Where the tables are LF-consistent over the
 // whole depth of the walk (run >= min(interval, p + 1), device_index.hip) this kernel produces exactly that:
+// (Elsewhere a row-by-row walk would NOT do: on tables with unordered ties the depth-first walk keeps following a
+// chain after it has surfaced -- a node is left only when it holds ONE row and that row is sampled, searcher.hpp:495 --
+// so one chain can surface twice and another never, and the count-based early exit, searcher.hpp:464, depends on the
+// order of all of it.  Measured on a tie-shuffled index: per-row walks lose hits the upstream walk reports.)
 // gather sa_full[lo..hi) (contiguous), read the up to 63 preceding bases of each hit from the text, sort, filter
 // (push_position, searcher.hpp:504-539), write.  One wave per read up to 256 rows, one workgroup above.  Reads with a row outside such a region, with more than
 // kSortMax rows, or on an index sampled wider than 64 go to the depth-first kernel (k_multi) instead.
