@@ -485,11 +485,10 @@ def main():
         nh_t = torch.where(uniq, torch.ones_like(idx), torch.where(multi_m, (w1 >> 40) & 0xFFFF, torch.zeros_like(idx)))
         plain_res[:, 2] = torch.where(uniq, idx, torch.where(multi_m & (nh_t > 0), n_reads + (w1 & m40), torch.zeros_like(idx)))
         plain_res[:, 3] = nh_t | (((meta >> 3) & 3) << 32)
-        plain_hits = torch.zeros((n_reads + int(n_hits), 2), dtype=torch.int64, device=dev)
-        plain_hits[:n_reads, 0] = torch.where(uniq, w1 & m40, torch.zeros_like(idx))
-        plain_hits[:n_reads, 1] = torch.where(uniq, ((w1 >> 40) & 0xFFFF) | (((meta >> 1) & 1) << 32), torch.zeros_like(idx))
-        if n_hits:
-            plain_hits[n_reads:] = hits.view(torch.int64).view(-1, 2)[: int(n_hits)]
+        # unique hits at their read's index; the lists stay where they are (hits[]), addressed behind the first n_reads slots
+        plain_hits = torch.zeros((n_reads, 2), dtype=torch.int64, device=dev)
+        plain_hits[:, 0] = torch.where(uniq, w1 & m40, torch.zeros_like(idx))
+        plain_hits[:, 1] = torch.where(uniq, ((w1 >> 40) & 0xFFFF) | (((meta >> 1) & 1) << 32), torch.zeros_like(idx))
         del rec, w0, w1, idx, nh_t
         if args.layout == "hits":
             # reads settled without an SA interval: the origin check below expects a size-1 interval for a hit
@@ -499,7 +498,7 @@ def main():
         hits_plain = plain_hits.view(-1).view(torch.uint8)
     else:
         n_no_sa = n_wide_rec = 0
-        results_plain, hits_plain = results, hits
+        results_plain, hits_plain = results, hits.view(-1)[: n_reads * 16]
         n_hits = n_hits - n_reads if n_hits >= n_reads else 0      # lists only, as in the compact layouts
     origin = None
     if origins is not None:
@@ -600,7 +599,13 @@ def main():
             tot = int(nh.sum())
             within = np.arange(tot) - np.repeat(np.cumsum(nh) - nh, nh)
             gi = torch.from_numpy((np.repeat(gres["first_hit"], nh) + within).astype(np.int64)).to(dev)
-            ghits = np.frombuffer(hits_plain.view(-1, 16)[gi].cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
+            # slots below n_reads: the unique hit of that read; above: the lists (hits[] itself in the compact layouts)
+            lists16 = hits.view(-1, 16)
+            list_base = 0 if compact else n_reads
+            in_list = gi >= n_reads
+            got = hits_plain.view(-1, 16)[torch.where(in_list, torch.zeros_like(gi), gi)]
+            got_l = lists16[torch.where(in_list, gi - n_reads + list_base, torch.zeros_like(gi))]
+            ghits = np.frombuffer(torch.where(in_list[:, None], got_l, got).cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
             oi = (np.repeat(first, nh) + within).astype(np.int64)
             ok = bool(np.array_equal(ghits, ohits[oi]))
         parity = {"reads_checked": probe_n, "identical": ok,

@@ -158,7 +158,7 @@ __device__ __forceinline__ void team_bitonic(uint64_t (&v)[4], uint32_t tid, uin
 constexpr uint64_t kPayOk = 1ull << 57;
 
 template <int T>
-__global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
+__global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;  // rows a team can sort
   // what is sorted is one 64-bit word per row: the first 24 prepended bases (48 bits) over the row's offset in
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
         if (!*s_bad) {
           // up to four rows per thread, phase by phase, so that the loads of all of them are in flight together
           uint64_t e4[4];
-          uint32_t tw[4][5];
+          uint4 tw[4][2];  // 32 bytes of textrc from a 16-byte boundary: two loads per row instead of five
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint32_t i = tid + (uint32_t)kk * T;
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
             const uint64_t p = e4[kk] & kPosMask;
             // text[p - 1 - k] = 3 - textrc[x0 + k]; a row without a position reads the start of the text
             const uint64_t x0 = e4[kk] == kNoPosition || p > m_text ? 0 : m_text - p;
-            const uint32_t* tx = ix.textrc + (x0 >> 4);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) tw[kk][q] = tx[q];
+            const uint4* tx = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
+            tw[kk][0] = tx[0];
+            tw[kk][1] = tx[1];
           }
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
@@ -272,12 +272,11 @@ __global__ __launch_bounds__(256) void k_multi_sort(const DeviceIndex ix, const 
                 *s_bad = 1u;  // benign race: every writer stores 1
               } else {
                 const uint64_t x0 = m_text - p;
-                const uint32_t sh = 2u * (uint32_t)(x0 & 15);
-                const uint64_t w0 = tw[kk][0] | ((uint64_t)tw[kk][1] << 32), w1 = tw[kk][2] | ((uint64_t)tw[kk][3] << 32), w2 = tw[kk][4];
                 sbwt_hit h;
                 const bool ok = push_position_keys(ix, t_chr, t_nk, t_nv, p, L, a.strand, &h);  // searcher.hpp:504-539
-                uint64_t c0 = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
-                uint64_t c1 = sh ? ((w1 >> sh) | (w2 << (64 - sh))) : w1;
+                uint64_t c0, c1;  // the 64 bases from x0 on, out of the 128 loaded from the 64-base boundary below it
+                sm_funnel128(u64_of(tw[kk][0].x, tw[kk][0].y), u64_of(tw[kk][0].z, tw[kk][0].w), u64_of(tw[kk][1].x, tw[kk][1].y),
+                             u64_of(tw[kk][1].z, tw[kk][1].w), (uint32_t)(x0 & 63), c0, c1);
                 c0 = ~c0;
                 c1 = ~c1;
                 if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; c1 = 0; }
