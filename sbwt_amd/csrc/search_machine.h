@@ -45,6 +45,22 @@ struct SmTables {  // LDS copies (or the global originals when they do not fit)
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
+// DPP moves inside a quad (lanes 4q .. 4q+3): full-rate VALU, no LDS
+template <int kSrc>
+__device__ __forceinline__ uint32_t quad_bcast_t(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kSrc * 0x55, 0xF, 0xF, true);  // quad_perm [k,k,k,k]
+}
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int k) {
+  switch (k) {
+    case 0: return quad_bcast_t<0>(v);
+    case 1: return quad_bcast_t<1>(v);
+    case 2: return quad_bcast_t<2>(v);
+    default: return quad_bcast_t<3>(v);
+  }
+}
+__device__ __forceinline__ uint32_t quad_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // [1,0,3,2]
+__device__ __forceinline__ uint32_t quad_swap2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }  // [2,3,0,1]
+
 // bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
 __device__ __forceinline__ void sm_funnel128(uint64_t q0, uint64_t q1, uint64_t q2, uint64_t q3, uint32_t o, uint64_t& c0,
                                              uint64_t& c1) {
@@ -234,7 +250,7 @@ constexpr uint32_t PF_P1 = 1024u, PF_RP1 = 2048u;             // (long-read vari
 // 64-base piece of its next read, and a text comparison that ends within the first 128 bases of the read runs in
 // ONE iteration against the whole 128-base window of the PosLine (instead of one iteration and one access per piece).
 template <bool kLds, bool kLong>
-__global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
+__global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, const SmArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_mem[];
   SmTables T{ix.chr_start, ix.npos_key, ix.npos_val, ix.sb_abs};
   const uint32_t n_super = (uint32_t)(((ix.n_blocks - 1) >> (kSuperShift - 6)) + 1);
@@ -570,12 +586,19 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
     const uint32_t vd = *pd;
     uint4 vh0 = make_uint4(0, 0, 0, 0), vh1 = vh0;
     if (H && !ix.hash_text) { vh0 = ph[0]; vh1 = ph[1]; }  // wave-uniform conditions; 8-byte slots: the bucket in two loads
+    uint64_t hq[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    uint32_t hwant[4] = {0, 0, 0, 0};
     if (H && ix.hash_text) {
-      // 16-byte slots (position word + the text k_settle compares): the four position words, 8 bytes each
-      const uint64_t* pw = reinterpret_cast<const uint64_t*>(ph);
-      const uint64_t q0 = pw[0], q1 = pw[2], q2 = pw[4], q3 = pw[6];
-      vh0 = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
-      vh1 = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
+      // 16-byte slots (position word + the text k_settle compares).  ONE load instruction per line (settle.h): in
+      // round k the four lanes of a quad read the four position words of the bucket its lane k asked for.
+      const uintptr_t pha = reinterpret_cast<uintptr_t>(ph);
+      const uint32_t rq = (pf & PF_RH1) ? 1u : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t a_lo = quad_bcast(pha & 0xFFFFFFFFu, k), a_hi = quad_bcast((uint32_t)(pha >> 32), k);
+        hwant[k] = quad_bcast(rq, k);
+        if (hwant[k]) hq[k] = reinterpret_cast<const uint64_t*>(u64_of(a_lo, a_hi))[2u * (lane & 3u)];
+      }
     }
     uint4 vr2 = make_uint4(0, 0, 0, 0);
     if (kLong) vr2 = *pr2;
@@ -601,17 +624,37 @@ __global__ __launch_bounds__(256) void k_search_sm(const DeviceIndex ix, const S
       nw2_hi = u64_of(vr2.z, vr2.w);
       pf = (pf | PF_P1) & ~PF_RP1;
     }
+    uint64_t hfound = ~0ull;
+    if (H && ix.hash_text) {  // wave-uniform: every lane takes part in the exchange
+      const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u;
+      const uint32_t tag = (uint32_t)hash_mix((~nw_lo) & hmask, H) & tmask;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t tag_k = quad_bcast(tag, k);
+        const uint32_t q_lo = (uint32_t)hq[k], q_hi = (uint32_t)(hq[k] >> 32);
+        const bool hit = hwant[k] && q_hi != 0xFFFFFFFFu && ((q_lo ^ tag_k) & tmask) == 0;
+        // at most one slot of a bucket carries the tag: OR the masked slot over the quad
+        uint32_t v0 = hit ? q_lo : 0u, v1 = hit ? q_hi : 0u, any = hit ? 1u : 0u;
+        v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); any |= quad_swap1(any);
+        v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); any |= quad_swap2(any);
+        if ((lane & 3u) == (uint32_t)k && any) hfound = u64_of(v0, v1);
+      }
+    }
     if (pf & PF_RH1) {
       // four slots: position << 24 | run << tag_bits | tag; an empty slot is all ones (no position is)
       const uint64_t vv = hash_mix((~nw_lo) & hmask, H);
       // (tag in the low word; the high word of an empty slot is all ones, that of a position never is)
       const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u, tag = (uint32_t)vv & tmask;
-      const uint32_t sl_lo[4] = {vh0.x, vh0.z, vh1.x, vh1.z};
-      const uint32_t sl_hi[4] = {vh0.y, vh0.w, vh1.y, vh1.w};
       uint64_t found = ~0ull;
+      if (!ix.hash_text) {
+        const uint32_t sl_lo[4] = {vh0.x, vh0.z, vh1.x, vh1.z};
+        const uint32_t sl_hi[4] = {vh0.y, vh0.w, vh1.y, vh1.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) found = u64_of(sl_lo[q], sl_hi[q]);
+        for (int q = 0; q < 4; ++q)
+          if (((sl_lo[q] ^ tag) & tmask) == 0 && sl_hi[q] != 0xFFFFFFFFu) found = u64_of(sl_lo[q], sl_hi[q]);
+      } else {
+        found = hfound;
+      }
       pf = (pf | PF_H1) & ~PF_RH1;
       tally_h += 0x10000u + (found != ~0ull ? 1u : 0u);
       if (found != ~0ull) {

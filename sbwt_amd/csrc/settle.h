@@ -38,22 +38,6 @@ struct SettleArgs {
   uint32_t ring_chr_max;                // chr_id a record holds (test knob, as in SmArgs)
 };
 
-// DPP moves inside a quad (lanes 4q .. 4q+3): full-rate VALU, no LDS
-template <int kSrc>
-__device__ __forceinline__ uint32_t quad_bcast_t(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kSrc * 0x55, 0xF, 0xF, true);  // quad_perm [k,k,k,k]
-}
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int k) {
-  switch (k) {
-    case 0: return quad_bcast_t<0>(v);
-    case 1: return quad_bcast_t<1>(v);
-    case 2: return quad_bcast_t<2>(v);
-    default: return quad_bcast_t<3>(v);
-  }
-}
-__device__ __forceinline__ uint32_t quad_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // [1,0,3,2]
-__device__ __forceinline__ uint32_t quad_swap2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }  // [2,3,0,1]
-
 constexpr uint32_t kSettleBuf = 512;  // pending indices a wave holds in LDS before it reserves list slots for them
 
 __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const SettleArgs a) {
