@@ -184,8 +184,11 @@ int sbwt_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t n_reads,
  * limit / strand are `sbwt map -m / -s` (main.cpp:167-168).
  * Layout of hits[]: the hit of a read with exactly one surviving hit lives at the read's own index
  * (first_hit == read index), so hits_cap must be at least n_reads; the lists of multi-hit reads follow behind
- * the first n_reads slots, each contiguous and in upstream emission order (first_hit says where).  Slots of
- * reads without a hit are not written.  *n_hits_host (host pointer, may be NULL) receives the number of slots
+ * the first n_reads slots, each contiguous and in upstream emission order (first_hit says where).  Multi-hit reads
+ * of one batch with the same SA interval and length have the same list (upstream would compute it once per read,
+ * searcher.hpp:424-503): it is located once and their records carry the SAME first_hit, so lists may alias --
+ * treat hits[] as read-only per read.  Slots of reads without a hit, and the slots reserved for reads that share
+ * another read's list, are not written.  *n_hits_host (host pointer, may be NULL) receives the number of slots
  * in use = n_reads + the multi-hit lists; on SBWT_ERR_CAPACITY it is what a retry needs. */
 int sbwt_map_batch_device(sbwt_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_lens, uint64_t n_reads,
                           uint32_t words_per_read, int limit, int strand, sbwt_read_result *d_results,
@@ -253,8 +256,9 @@ int sbwt_ctx_last_timing_ex(const sbwt_ctx *ctx, float *ms, uint32_t n);
 int sbwt_ctx_last_stats(const sbwt_ctx *ctx, uint64_t stats[4]);
 /* The same and more: the first n counters of [0..3] as above, [4] hash_tab lookups the search kernel made, [5] those
  * that found their search prefix in it (the hash hit rate of a workload), [6] index lines the hits-only
- * fast pass (k_settle) read, [7] reads it left to the general kernels; counters beyond the ones the library knows
- * read 0. */
+ * fast pass (k_settle) read, [7] reads it left to the general kernels, [8] multi-hit reads whose record
+ * points at the list of another read of the batch with the same interval and length instead of a list of their own
+ * (see first_hit); counters beyond the ones the library knows read 0. */
 int sbwt_ctx_last_stats_ex(const sbwt_ctx *ctx, uint64_t *stats, uint32_t n);
 /* The random-access roofline of the device, measured over the index's own largest table ("a random
  * granule gather microbenchmark over a table of the same footprint on the same GPU"): every lane walks

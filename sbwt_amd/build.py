@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
         if force or _stale(obj, [path] + headers):
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+            cmd = [hipcc] + FLAGS + os.environ.get("SBWT_CXXFLAGS", "").split() + ["-x", "hip", "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

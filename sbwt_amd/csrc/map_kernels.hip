@@ -39,6 +39,7 @@ struct Counters {
   unsigned long long wide_count;      // compact output: results that went to wide[]
   unsigned long long pending_count;   // k_settle: reads left to the general kernels
   unsigned long long pending_other;   // ... of which not because their prefix is missing from hash_tab
+  unsigned long long shared_count;    // multi-hit reads whose record points at the list of another read with the same interval (k_multi_share)
 };
 
 struct MapArgs {
@@ -160,7 +161,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 8;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 9;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -177,6 +178,9 @@ struct MapWork {
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
   size_t sort_lds_bytes = 0;                  // filter tables of k_multi_sort in LDS (0: they stay in global memory)
+  unsigned long long* d_group_keys = nullptr; // grouping of multi-hit reads with one interval and length (multi_locate.h)
+  uint32_t* d_group_leader = nullptr;
+  uint32_t group_slots = 0;                   // a power of two; 0: no grouping (the no-allocation entry point)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // null: the pass is not timed
 };
 
@@ -186,7 +190,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -245,6 +249,13 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&c->d_dfs_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess && ix->d.hash_text) e = hipMalloc(&c->d_pend_list, max_reads * sizeof(uint32_t));
+  if (e == hipSuccess && !getenv("SBWT_NO_SHARED_LISTS")) {
+    uint32_t slots = 1u << 12;
+    while (slots < max_reads && slots < (1u << 23)) slots <<= 1;
+    e = hipMalloc(&c->d_group_keys, (size_t)slots * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_group_leader, (size_t)slots * sizeof(uint32_t));
+    if (e == hipSuccess) c->group_slots = slots;
+  }
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev_s[k]);
   if (e == hipSuccess) {
     int per_cu = 0;
@@ -281,6 +292,8 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   if (c->h_ctr) hipHostFree(c->h_ctr);
   hipFree(c->d_queue);
   hipFree(c->d_dfs_queue);
+  hipFree(c->d_group_keys);
+  hipFree(c->d_group_leader);
   hipFree(c->d_wave_info);
   hipFree(c->d_stacks);
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits); hipFree(c->d_wide);
@@ -458,16 +471,49 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     ms.dfs_queue = w.d_dfs_queue;
     ms.dfs_count = &w.d_ctr->dfs_count;
     ms.lds_tables = w.sort_lds_bytes ? 1u : 0u;
+    ms.shared_count = &w.d_ctr->shared_count;
+    ms.grp.keys = nullptr;
+    ms.grp.leader = nullptr;
+    ms.grp.mask = 0;
+    if (w.group_slots) {
+      uint32_t slots = 1u << 12;  // as many as this batch can fill, at most what the ctx holds
+      while (slots < n_reads && slots < w.group_slots) slots <<= 1;
+      if (slots > w.group_slots) slots = w.group_slots;
+      ms.grp.keys = w.d_group_keys;
+      ms.grp.leader = w.d_group_leader;
+      ms.grp.mask = slots - 1u;
+      SBWT_HIP(hipMemsetAsync(w.d_group_keys, 0xFF, (size_t)slots * sizeof(unsigned long long), w.stream));
+      SBWT_HIP(hipMemsetAsync(w.d_group_leader, 0xFF, (size_t)slots * sizeof(uint32_t), w.stream));
+      k_multi_group<<<n_waves, 256, 0, w.stream>>>(ms);
+      SBWT_LAUNCHED();
+    }
     k_multi_sort<64><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
     k_multi_sort<256><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
     SBWT_LAUNCHED();
     k_multi<<<w.multi_lanes / 256, 256, 0, w.stream>>>(d, a, w.d_stacks, w.multi_lanes, w.d_dfs_queue, &w.d_ctr->dfs_count);
     SBWT_LAUNCHED();
+    if (w.group_slots) {
+      k_multi_share<<<n_waves, 256, 0, w.stream>>>(ms);
+      SBWT_LAUNCHED();
+    }
   }
   if (timed) SBWT_HIP(hipEventRecord(w.ev[2], w.stream));
   SBWT_HIP(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, w.stream));
   SBWT_HIP(hipStreamSynchronize(w.stream));
   SBWT_HIP(hipGetLastError());
+#ifdef SBWT_PHASE_CLOCKS
+  {
+    unsigned long long ph[24] = {0}, zero[24] = {0};
+    SBWT_HIP(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_multi_phase), sizeof(ph)));
+    SBWT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_multi_phase), zero, sizeof(zero)));
+    fprintf(stderr, "k_multi_sort phase clocks (scan, record, sa_full, text, keys, decide, radix, compare-sort, write | reads, radix reads)\n");
+    for (int t = 0; t < 2; ++t) {
+      fprintf(stderr, "  T=%d:", t ? 256 : 64);
+      for (int k = 0; k < 9; ++k) fprintf(stderr, " %.3g", (double)ph[12 * t + k]);
+      fprintf(stderr, " | %llu %llu\n", ph[12 * t + 10], ph[12 * t + 11]);
+    }
+  }
+#endif
   if (ms_out) {
     float ms[3] = {0, 0, 0};
     if (timed) {
@@ -483,6 +529,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     stats_out[3] = (accumulate ? stats_out[3] : 0) + w.h_ctr->dfs_count;
     stats_out[4] = (accumulate ? stats_out[4] : 0) + w.h_ctr->hash_stats[0];
     stats_out[5] = (accumulate ? stats_out[5] : 0) + w.h_ctr->hash_stats[1];
+    stats_out[8] = (accumulate ? stats_out[8] : 0) + w.h_ctr->shared_count;
   }
   *multi_used = w.h_ctr->hit_count;
   if (wide_used) *wide_used = w.h_ctr->wide_count;
@@ -566,7 +613,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     SBWT_LAUNCHED();
     const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, 4, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
@@ -577,13 +624,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8]};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }

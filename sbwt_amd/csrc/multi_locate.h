@@ -25,6 +25,54 @@
 namespace sbwt {
 
 constexpr uint32_t kSortMax = 1024;
+constexpr uint32_t kRadixMaxPasses = 8;  // differing key digits up to which the stable radix passes beat the comparison sort
+
+// Reads with the same interval and length have the same hit list (the list is a function of the rows, the read
+// length, the strand option and the limit): small-RNA batches hold the same molecule many times over.  The queued
+// reads are grouped through a hash table keyed by (lo, rows, length); one member -- the
+// leader -- is located, and k_multi_share points the records of the others at its list.  A read the table has no room for (kGroupProbes
+// slots taken by other keys) simply leads itself.  Upstream locates every read (searcher.hpp:424-503): same output.
+struct GroupArgs {
+  unsigned long long* keys;  // null: no grouping
+  uint32_t* leader;          // of the key in the same slot: group_scramble(read index) of its leader
+  uint32_t mask;             // slots - 1 (a power of two)
+};
+constexpr uint32_t kGroupProbes = 16;
+// The leader is the member with the smallest SCRAMBLED index (a bijection of the 32-bit indices): leaders chosen by
+// smallest index would crowd the first part of the batch, i.e. the queue chunks of a few workgroups of k_multi_sort.
+__device__ __forceinline__ uint32_t group_scramble(uint32_t r) { return r * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t group_unscramble(uint32_t v) { return v * 0x0E8B2F51u; }
+constexpr unsigned long long kGroupEmpty = ~0ull;
+
+__device__ __forceinline__ bool group_key(uint64_t lo, uint64_t rows, uint32_t L, unsigned long long& key) {
+  if (rows >= 4096u || L >= 4095u) return false;
+  key = lo | (rows << kPosBits) | ((unsigned long long)L << (kPosBits + 12));
+  return true;
+}
+__device__ __forceinline__ uint32_t group_hash(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return (uint32_t)(z ^ (z >> 31));
+}
+// slot of `key`, ~0u when it is not in the table (keys are only ever added: an empty slot ends the probe)
+__device__ __forceinline__ uint32_t group_find(const GroupArgs& g, unsigned long long key) {
+  const uint32_t h0 = group_hash(key);
+  for (uint32_t i = 0; i < kGroupProbes; ++i) {
+    const uint32_t h = (h0 + i) & g.mask;
+    const unsigned long long k = g.keys[h];
+    if (k == key) return h;
+    if (k == kGroupEmpty) break;
+  }
+  return ~0u;
+}
+// read index of the leader of read r's group (r itself when it has none)
+__device__ __forceinline__ uint32_t group_leader(const GroupArgs& g, uint32_t r, uint64_t lo, uint64_t rows, uint32_t L) {
+  unsigned long long key;
+  if (!g.keys || !group_key(lo, rows, L, key)) return r;
+  const uint32_t h = group_find(g, key);
+  return h == ~0u ? r : group_unscramble(g.leader[h]);
+}
 
 struct MultiSortArgs {
   const uint32_t* lens;
@@ -41,6 +89,8 @@ struct MultiSortArgs {
   uint32_t lds_tables;                   // the launch carries (n_chr + 2 n_npos) * 8 bytes of dynamic LDS for the filter tables
   uint32_t* dfs_queue;                   // reads this kernel hands on to k_multi
   unsigned long long* dfs_count;
+  GroupArgs grp;
+  unsigned long long* shared_count;      // reads whose record points at their leader's list (k_multi_share)
 };
 
 // Turns the per-wave totals of k_search_sm into global offsets: exclusive prefix sums of the hit slots and of the
@@ -75,6 +125,76 @@ __global__ __launch_bounds__(1024) void k_multi_plan(WaveInfo* __restrict__ wi, 
     *total_count = pc;
     if (multi_base + ps > hits_cap) *overflow = 1u;
   }
+}
+
+// every queued read enters its key; the slot's leader becomes the member with the smallest scrambled index
+__global__ __launch_bounds__(256) void k_multi_group(const MultiSortArgs a) {
+  if (*a.overflow) return;
+  for (uint32_t w = blockIdx.x; w < a.n_waves; w += gridDim.x) {
+    const uint32_t count = a.wave_info[w].count;
+    for (uint32_t q = threadIdx.x; q < count; q += blockDim.x) {
+      const uint32_t r = a.queue[(uint64_t)w * a.chunk + q];
+      const MultiRead mr = rio_load(a.io, r);
+      unsigned long long key;
+      if (!group_key(mr.lo, mr.hi - mr.lo, a.lens[r], key)) continue;
+      const uint32_t h0 = group_hash(key);
+      for (uint32_t i = 0; i < kGroupProbes; ++i) {
+        const uint32_t h = (h0 + i) & a.grp.mask;
+        const unsigned long long prev = atomicCAS(&a.grp.keys[h], kGroupEmpty, key);
+        if (prev == kGroupEmpty || prev == key) {
+          atomicMin(&a.grp.leader[h], group_scramble(r));
+          break;
+        }
+      }
+    }
+  }
+}
+
+// where a located read's list is, how many hits it holds, and the flag the locate may have added
+__device__ __forceinline__ void rio_load_list(const ResultIO& io, uint64_t r, uint64_t& first_hit, int32_t& nh, uint32_t& truncated) {
+  if (!io.compact) {
+    const sbwt_read_result res = io.results[r];
+    first_hit = res.first_hit; nh = res.nh; truncated = res.flags & SBWT_RF_TRUNCATED;
+    return;
+  }
+  const uint64_t w1 = io.compact[r].w1;
+  if ((uint32_t)(w1 >> 56) & SBWT_CR_WIDE) {
+    first_hit = 0; nh = 0; truncated = 0;
+    const uint64_t slot = w1 & kPosMask;
+    if (slot < io.wide_cap) {
+      const sbwt_read_result res = io.wide[slot].r;
+      first_hit = res.first_hit; nh = res.nh; truncated = res.flags & SBWT_RF_TRUNCATED;
+    }
+    return;
+  }
+  first_hit = w1 & kPosMask;
+  nh = (int32_t)((w1 >> kPosBits) & 0xFFFFull);
+  truncated = ((uint32_t)(w1 >> 56) & SBWT_CR_TRUNCATED) ? SBWT_RF_TRUNCATED : 0u;
+}
+
+// after the locate kernels: the members of a group that are not its leader point their record at the leader's list
+// (hits[first_hit .. first_hit + nh) of reads with one interval and length is one range; the slots reserved for the
+// followers stay unused)
+__global__ __launch_bounds__(256) void k_multi_share(const MultiSortArgs a) {
+  if (*a.overflow) return;
+  uint32_t shared = 0;
+  for (uint32_t w = blockIdx.x; w < a.n_waves; w += gridDim.x) {
+    const uint32_t count = a.wave_info[w].count;
+    for (uint32_t q = threadIdx.x; q < count; q += blockDim.x) {
+      const uint32_t r = a.queue[(uint64_t)w * a.chunk + q];
+      const MultiRead mr = rio_load(a.io, r);
+      const uint32_t lead = group_leader(a.grp, r, mr.lo, mr.hi - mr.lo, a.lens[r]);
+      if (lead == r) continue;
+      uint64_t first;
+      int32_t nh;
+      uint32_t truncated;
+      rio_load_list(a.io, lead, first, nh, truncated);
+      rio_store_multi(a.io, r, first, true, nh, truncated);
+      ++shared;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) shared += (uint32_t)__shfl_xor((int)shared, d);
+  if ((threadIdx.x & 63) == 0 && shared) atomicAdd(a.shared_count, (unsigned long long)shared);
 }
 
 // 2-bit groups of x in reverse order (first base most significant)
@@ -157,16 +277,29 @@ __device__ __forceinline__ void team_bitonic(uint64_t (&v)[4], uint32_t tid, uin
 // pos0 (40 bits) | chr_id << 40 (16 bits) | is_rc << 56 | passed the filters << 57 | t << 58 (6 bits)
 constexpr uint64_t kPayOk = 1ull << 57;
 
+// -DSBWT_PHASE_CLOCKS: thread 0 of every team adds the clocks each phase of a read took to g_multi_phase[] (a
+// development aid; map_pass prints the totals)
+#ifdef SBWT_PHASE_CLOCKS
+__device__ unsigned long long g_multi_phase[24];  // [0..12) wave teams, [12..24) workgroup teams
+#define SBWT_PHASE(k) do { const unsigned long long c_ = clock64(); if (tid == 0) s_phase[team][k] += c_ - ph_t; ph_t = c_; } while (0)
+#define SBWT_PHASE_MEM(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SBWT_PHASE(k); } while (0)
+#else
+#define SBWT_PHASE(k) do { } while (0)
+#define SBWT_PHASE_MEM(k) do { } while (0)
+#endif
+
 template <int T>
-__global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
+__global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;  // rows a team can sort
   // what is sorted is one 64-bit word per row: the first 24 prepended bases (48 bits) over the row's offset in
   // the interval (16 bits).  Rows whose first 24 bases agree are compared in full through the offset (rare).
-  __shared__ uint64_t s_k0[kSortMax], s_k1[kSortMax], s_key[kSortMax], s_pay[kSortMax];
+  __shared__ __attribute__((aligned(16))) uint64_t s_k0[kSortMax], s_k1[kSortMax], s_key[kSortMax], s_pay[kSortMax];
   __shared__ uint32_t s_list_all[256];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_bad_all[4];
+  __shared__ uint16_t s_ord_all[2][kSortMax];  // radix path: row offsets in emission order so far, ping-pong
+  __shared__ uint64_t s_red_all[4][5];          // radix path: OR / AND of the key words over a wave's rows
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];  // (n_chr + 2 n_npos) words when a.lds_tables
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
   // push_position tables: LDS copies when they fit
@@ -182,12 +315,22 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
   }
   const uint32_t team = threadIdx.x / T, tid = threadIdx.x % T;
   const uint32_t lane = threadIdx.x & 63;
+#ifdef SBWT_PHASE_CLOCKS
+  __shared__ unsigned long long s_phase[4][12];  // same-address global atomics per read would dominate what is measured
+  if (tid < 12) s_phase[team][tid] = 0;
+  team_sync<T>();
+  unsigned long long ph_t = clock64();
+#endif
   uint64_t* k0 = s_k0 + team * kCap;
   uint64_t* k1 = s_k1 + team * kCap;
   uint64_t* key = s_key + team * kCap;
   uint64_t* pay = s_pay + team * kCap;
   uint32_t* list = s_list_all + team * T;
   uint32_t* s_bad = s_bad_all + team;
+  uint16_t* ord_a = s_ord_all[0] + team * kCap;
+  uint16_t* ord_b = s_ord_all[1] + team * kCap;
+  constexpr uint32_t kWaveRows = kCap / 64;  // 64-row groups of a team's rows: the unit the radix passes rank in
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
   const uint64_t m_text = ix.n - 1;
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
   // full order of two rows given their offsets: prepended string (zero padded), its length, the offset
@@ -212,6 +355,7 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
         const MultiRead mr = rio_load(a.io, my_r);
         const uint64_t m = mr.hi - mr.lo;
         mine = T == 64 ? m <= kCap : m > kSortMax / 4;
+        if (mine && a.grp.keys) mine = group_leader(a.grp, my_r, mr.lo, m, a.lens[my_r]) == my_r;
       }
       uint32_t n_list;
       {
@@ -230,6 +374,7 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
         if (mine) list[off] = my_r;
       }
       team_sync<T>();
+      SBWT_PHASE(0);
       for (uint32_t li = 0; li < n_list; ++li) {
         const uint32_t r = list[li];
         MultiRead res = rio_load(a.io, r);
@@ -240,24 +385,63 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
         team_sync<T>();
         uint32_t N = 64;
         while (N < m && N < kCap) N <<= 1;
+        SBWT_PHASE_MEM(1);
+        uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;  // over this thread's rows: which key bits differ
+        uint32_t ort = 0, andt = ~0u;
         if (!*s_bad) {
           // up to four rows per thread, phase by phase, so that the loads of all of them are in flight together
           uint64_t e4[4];
-          uint4 tw[4][2];  // 32 bytes of textrc from a 16-byte boundary: two loads per row instead of five
+          uint4 tw[4][2];  // 32 bytes of textrc from a 16-byte boundary around the row's left context
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint32_t i = tid + (uint32_t)kk * T;
             e4[kk] = i < m ? ix.sa_full[lo + i] : kNoPosition;
           }
+          SBWT_PHASE_MEM(2);
+          // ONE load instruction per line (settle.h): the two 16-byte halves of a row's window are fetched by the two
+          // lanes of a pair in the same instruction -- round h serves the row of the pair's lane h -- and a DPP swap
+          // hands the partner's half over.  (A lane loading both halves itself keeps the second load waiting in the
+          // vector cache behind the first one's miss.)
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint64_t p = e4[kk] & kPosMask;
             // text[p - 1 - k] = 3 - textrc[x0 + k]; a row without a position reads the start of the text
             const uint64_t x0 = e4[kk] == kNoPosition || p > m_text ? 0 : m_text - p;
-            const uint4* tx = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
-            tw[kk][0] = tx[0];
-            tw[kk][1] = tx[1];
+            const uintptr_t tx = reinterpret_cast<uintptr_t>(reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6));
+            const uint32_t tx_lo = (uint32_t)tx, tx_hi = (uint32_t)(tx >> 32);
+            const uintptr_t t0 = u64_of(pair_bcast<0>(tx_lo), pair_bcast<0>(tx_hi)), t1 = u64_of(pair_bcast<1>(tx_lo), pair_bcast<1>(tx_hi));
+            const uint4 r0 = reinterpret_cast<const uint4*>(t0)[lane & 1u];
+            const uint4 r1 = reinterpret_cast<const uint4*>(t1)[lane & 1u];
+            const uint4 s0 = make_uint4(quad_swap1(r0.x), quad_swap1(r0.y), quad_swap1(r0.z), quad_swap1(r0.w));
+            const uint4 s1 = make_uint4(quad_swap1(r1.x), quad_swap1(r1.y), quad_swap1(r1.z), quad_swap1(r1.w));
+            tw[kk][0] = (lane & 1u) ? s1 : r0;
+            tw[kk][1] = (lane & 1u) ? r1 : s0;
           }
+          SBWT_PHASE_MEM(3);
+          // filters (push_position, searcher.hpp:504-539): the table searches of the four rows run interleaved
+          uint64_t fpos[4] = {0, 0, 0, 0};
+          uint32_t c1[4], n1[4];
+          bool frc[4], fgo[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t i = tid + (uint32_t)kk * T;
+            const uint64_t e = e4[kk], p = e & kPosMask;
+            const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
+            frc[kk] = false;
+            fgo[kk] = false;
+            if (i < m) {
+              if (e == kNoPosition || (e >> kPosBits) < need) {
+                *s_bad = 1u;  // benign race: every writer stores 1
+              } else {
+                fpos[kk] = p;
+                fgo[kk] = push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
+                if (!fgo[kk]) fpos[kk] = 0;
+              }
+            }
+          }
+          upper_bound_minus1_x4(t_chr, ix.n_chr, fpos, c1);
+          upper_bound_minus1_x4(t_nk, ix.n_npos, fpos, n1);
+          const bool pow2 = (ix.interval & (ix.interval - 1u)) == 0;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint32_t i = tid + (uint32_t)kk * T;
@@ -265,27 +449,26 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
             uint64_t h0 = ~0ull, h1 = ~0ull, py = 63ull << 58;
             if (i < m) {
               const uint64_t e = e4[kk];
-              const uint64_t p = e & kPosMask, run = e >> kPosBits;
-              const uint32_t t = (uint32_t)(p % ix.interval);
+              const uint64_t p = e & kPosMask;
+              const uint32_t t = pow2 ? (uint32_t)p & (ix.interval - 1u) : (uint32_t)(p % ix.interval);
               const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
-              if (e == kNoPosition || run < need) {
-                *s_bad = 1u;  // benign race: every writer stores 1
-              } else {
+              if (!(e == kNoPosition || (e >> kPosBits) < need)) {
                 const uint64_t x0 = m_text - p;
                 sbwt_hit h;
-                const bool ok = push_position_keys(ix, t_chr, t_nk, t_nv, p, L, a.strand, &h);  // searcher.hpp:504-539
-                uint64_t c0, c1;  // the 64 bases from x0 on, out of the 128 loaded from the 64-base boundary below it
+                const bool ok = fgo[kk] && push_position_finish(ix, t_chr, t_nk, t_nv, fpos[kk], L, frc[kk], c1[kk], n1[kk], &h);
+                uint64_t c0, cc1;  // the 64 bases from x0 on, out of the 128 loaded from the 64-base boundary below it
                 sm_funnel128(u64_of(tw[kk][0].x, tw[kk][0].y), u64_of(tw[kk][0].z, tw[kk][0].w), u64_of(tw[kk][1].x, tw[kk][1].y),
-                             u64_of(tw[kk][1].z, tw[kk][1].w), (uint32_t)(x0 & 63), c0, c1);
+                             u64_of(tw[kk][1].z, tw[kk][1].w), (uint32_t)(x0 & 63), c0, cc1);
                 c0 = ~c0;
-                c1 = ~c1;
-                if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; c1 = 0; }
-                else if (t < 64u) c1 &= t > 32u ? ((1ull << (2 * (t - 32u))) - 1ull) : 0ull;
+                cc1 = ~cc1;
+                if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; cc1 = 0; }
+                else if (t < 64u) cc1 &= t > 32u ? ((1ull << (2 * (t - 32u))) - 1ull) : 0ull;
                 h0 = rev_bases(c0);
-                h1 = rev_bases(c1);
+                h1 = rev_bases(cc1);
                 py = ((uint64_t)t << 58);
                 if (ok && h.pos0 > kPosMask) *s_bad = 1u;  // (an upstream-accepted wrapped position: the depth-first kernel writes whole hits)
                 if (ok) py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+                or0 |= h0; and0 &= h0; or1 |= h1; and1 &= h1; ort |= t; andt &= t;
               }
             }
             k0[i] = h0; k1[i] = h1; pay[i] = py;
@@ -293,6 +476,7 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
           }
         }
         team_sync<T>();
+        SBWT_PHASE(4);
         if (*s_bad) {
           if (tid == 0) {
             rio_store_multi(a.io, r, res.first_hit, false, 0, 0u);
@@ -301,6 +485,118 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
           team_sync<T>();
           continue;
         }
+        // Which 8-bit digits of the full key -- k0 | k1 | t, 17 digits -- differ between the rows of this read?  The
+        // emission order is the order of the full keys with ties in row order, i.e. what a STABLE sort by those digits
+        // alone gives.  Copies of a repeat share most of their left context (the repeat itself), so few digits
+        // differ: one stable counting pass per differing digit, least significant first, instead of a comparison
+        // sort whose every comparison of two such rows has to go through the full keys.
+        bool radix;
+        uint32_t dmask = 0;  // bit d: digit d differs (0 = the first four bases ... 15 = bases 60..63, 16 = t)
+        {
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) {
+            or0 |= shfl_xor64(or0, (uint32_t)d); and0 &= shfl_xor64(and0, (uint32_t)d);
+            or1 |= shfl_xor64(or1, (uint32_t)d); and1 &= shfl_xor64(and1, (uint32_t)d);
+            ort |= (uint32_t)__shfl_xor((int)ort, d); andt &= (uint32_t)__shfl_xor((int)andt, d);
+          }
+          if (T == 256) {
+            uint64_t* red = s_red_all[threadIdx.x >> 6];
+            if (lane == 0) { red[0] = or0; red[1] = and0; red[2] = or1; red[3] = and1; red[4] = u64_of(ort, andt); }
+            __syncthreads();
+            for (uint32_t v = 0; v < 4; ++v) {
+              or0 |= s_red_all[v][0]; and0 &= s_red_all[v][1]; or1 |= s_red_all[v][2]; and1 &= s_red_all[v][3];
+              ort |= (uint32_t)s_red_all[v][4]; andt &= (uint32_t)(s_red_all[v][4] >> 32);
+            }
+          }
+          const uint64_t v0 = or0 & ~and0, v1 = or1 & ~and1;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            if ((v0 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << b;
+            if ((v1 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << (8 + b);
+          }
+          if (ort & ~andt) dmask |= 1u << 16;
+          dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)dmask);
+          radix = __popc(dmask) <= (int)kRadixMaxPasses;
+        }
+        SBWT_PHASE(5);
+        const uint16_t* ord = nullptr;  // radix path: row offsets in emission order
+        if (radix) {
+          uint16_t* oin = ord_a;
+          uint16_t* oout = ord_b;
+          for (uint32_t k = tid; k < m; k += T) oin[k] = (uint16_t)k;
+          team_sync<T>();
+          uint16_t* const h16 = reinterpret_cast<uint16_t*>(key);  // [256 digits][kWaveRows]: the sort words are not needed here
+          for (int d = 16; d >= 0; --d) {
+            if (!((dmask >> d) & 1u)) continue;
+            for (uint32_t k = tid; k < kCap * 2u; k += T) reinterpret_cast<uint32_t*>(key)[k] = 0u;
+            team_sync<T>();
+            uint32_t dig[4], rnk[4], idx[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
+              dig[kk] = 0; rnk[kk] = 0; idx[kk] = 0;
+              if (wr * 64u >= m) continue;  // wave-uniform
+              const bool valid = j < m;
+              if (valid) {
+                idx[kk] = oin[j];
+                dig[kk] = d == 16 ? (uint32_t)(pay[idx[kk]] >> 58)
+                                  : (uint32_t)((d >= 8 ? k1[idx[kk]] : k0[idx[kk]]) >> (56 - 8 * (d & 7))) & 0xFFu;
+              }
+              // lanes of this 64-row group with the same digit; a row's place among them
+              uint64_t peers = __ballot(valid);
+#pragma unroll
+              for (int b = 0; b < 8; ++b) {
+                const bool bit = (dig[kk] >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+              }
+              rnk[kk] = (uint32_t)__popcll(peers & lane_lt);
+              if (valid && rnk[kk] == 0) h16[dig[kk] * kWaveRows + wr] = (uint16_t)__popcll(peers);
+            }
+            team_sync<T>();
+            {
+              // exclusive prefix sums in (digit, group) order: 16 consecutive counters per thread, then over threads
+              uint4* hq = reinterpret_cast<uint4*>(key) + 2u * tid;
+              uint4 qa = hq[0], qb = hq[1];
+              uint32_t w8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+              uint32_t run = 0;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const uint32_t c_lo = w8[k] & 0xFFFFu, c_hi = w8[k] >> 16;
+                w8[k] = run | ((run + c_lo) << 16);
+                run += c_lo + c_hi;
+              }
+              uint32_t inc = run;
+#pragma unroll
+              for (int s = 1; s < 64; s <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, s);
+                if (lane >= (uint32_t)s) inc += o;
+              }
+              uint32_t base = inc - run;
+              if (T == 256) {
+                const uint32_t wave = threadIdx.x >> 6;
+                if (lane == 63) s_scan_all[wave] = inc;
+                __syncthreads();
+                for (uint32_t v = 0; v < wave; ++v) base += s_scan_all[v];
+              }
+              const uint32_t b2 = base | (base << 16);
+              hq[0] = make_uint4(w8[0] + b2, w8[1] + b2, w8[2] + b2, w8[3] + b2);
+              hq[1] = make_uint4(w8[4] + b2, w8[5] + b2, w8[6] + b2, w8[7] + b2);
+            }
+            team_sync<T>();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
+              if (j < m) oout[(uint32_t)h16[dig[kk] * kWaveRows + wr] + rnk[kk]] = (uint16_t)idx[kk];
+            }
+            team_sync<T>();
+            uint16_t* const sw = oin; oin = oout; oout = sw;
+          }
+          ord = oin;
+          N = 0;
+          SBWT_PHASE(6);
+        }
+        if (!radix) {
         // Rows whose left contexts agree over their whole length (copies of a repeat at the same phase of the
         // sampling, say) are in emission order as they stand, and every comparison among them would take the
         // full-key path: one pass finds out whether the words are in order already.
@@ -338,13 +634,15 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
             team_sync<T>();
           }
         }
+          SBWT_PHASE(7);
+        }
         // rows in emission order: compact those that passed the filters, write
         sbwt_hit* out = a.hits + res.first_hit;
         uint32_t base = 0;
         for (uint32_t c = 0; c < m; c += T) {
           const uint32_t k = c + tid;
           uint64_t py = 0;
-          if (k < m) py = pay[(uint32_t)key[k] & 0xFFFFu];
+          if (k < m) py = pay[ord ? (uint32_t)ord[k] : ((uint32_t)key[k] & 0xFFFFu)];
           const bool ok = (py & kPayOk) != 0;
           sbwt_hit h;
           h.pos0 = py & kPosMask;
@@ -367,9 +665,17 @@ __global__ __launch_bounds__(256, 4) void k_multi_sort(const DeviceIndex ix, con
         }
         if (tid == 0) rio_store_multi(a.io, r, res.first_hit, true, (int32_t)base, 0u);
         team_sync<T>();
+        SBWT_PHASE(8);
+#ifdef SBWT_PHASE_CLOCKS
+        if (tid == 0) { s_phase[team][10] += 1; s_phase[team][11] += radix ? 1 : 0; }
+#endif
       }
     }
   }
+#ifdef SBWT_PHASE_CLOCKS
+  team_sync<T>();
+  if (tid < 12) atomicAdd(&g_multi_phase[(T == 256 ? 12 : 0) + tid], s_phase[team][tid]);
+#endif
 }
 
 }  // namespace sbwt

@@ -111,18 +111,38 @@ __device__ __forceinline__ uint32_t upper_bound_minus1(const uint64_t* __restric
 // table carries -- the up to 11 end-of-text suffixes shorter than 12 sit at the end of the preceding 12-mer's
 // bucket, a hit built on one has p + L > 2 * real_size and `position` underflows (unsigned, as
 // upstream's INTTYPE does) -- and then both ends are looked up as upstream does, on the wrapped values.
-__device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos_key,
-                                                   const uint64_t* npos_val, uint64_t position, uint32_t L, int strand,
-                                                   sbwt_hit* out) {
-  bool is_rc = false;
+// The same for four keys at once, as fixed-length binary lifting: the steps of the four searches interleave, so a
+// step costs one table latency (LDS or cache), not four, and no lane diverges.
+__device__ __forceinline__ void upper_bound_minus1_x4(const uint64_t* __restrict__ keys, uint32_t n, const uint64_t (&x)[4],
+                                                      uint32_t (&out)[4]) {
+  uint32_t cnt[4] = {0, 0, 0, 0};  // keys known to be <= x
+  for (uint32_t step = n ? 1u << (31 - __clz((int)n)) : 0u; step; step >>= 1) {
+    uint64_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = keys[(cnt[k] + step <= n ? cnt[k] + step : n) - 1u];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (cnt[k] + step <= n && v[k] <= x[k]) cnt[k] += step;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = cnt[k] - 1u;  // keys[0] = 0 <= x: cnt >= 1
+}
+
+// searcher.hpp:504-518: orientation of a text position; false when the strand option drops it
+__device__ __forceinline__ bool push_position_orient(const DeviceIndex& ix, uint64_t& position, uint32_t L, int strand, bool& is_rc) {
+  is_rc = false;
   if (position >= ix.real_size) {
     is_rc = true;
     position = ix.real_size * 2 - position - L;
   }
-  if ((strand == 0 && !is_rc) || (strand == 1 && is_rc)) return false;
+  return !((strand == 0 && !is_rc) || (strand == 1 && is_rc));
+}
+
+// searcher.hpp:519-539 once upper_bound - 1 of the first base is known in both maps (c1, n1)
+__device__ __forceinline__ bool push_position_finish(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos_key,
+                                                     const uint64_t* npos_val, uint64_t position, uint32_t L, bool is_rc,
+                                                     uint32_t c1, uint32_t n1, sbwt_hit* out) {
   const uint64_t last = position + L - 1;
-  const uint32_t c1 = upper_bound_minus1(chr, ix.n_chr, position);
-  const uint32_t n1 = upper_bound_minus1(npos_key, ix.n_npos, position);
   if (last >= position) {
     if (c1 + 1 < ix.n_chr && chr[c1 + 1] <= last) {
       if (!ix.chr_class) return false;
@@ -139,6 +159,16 @@ __device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const 
   out->chr_id = c1;
   out->is_rc = is_rc ? 1u : 0u;
   return true;
+}
+
+__device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const uint64_t* chr, const uint64_t* npos_key,
+                                                   const uint64_t* npos_val, uint64_t position, uint32_t L, int strand,
+                                                   sbwt_hit* out) {
+  bool is_rc;
+  if (!push_position_orient(ix, position, L, strand, is_rc)) return false;
+  const uint32_t c1 = upper_bound_minus1(chr, ix.n_chr, position);
+  const uint32_t n1 = upper_bound_minus1(npos_key, ix.n_npos, position);
+  return push_position_finish(ix, chr, npos_key, npos_val, position, L, is_rc, c1, n1, out);
 }
 __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
                                                    sbwt_hit* out) {

@@ -61,6 +61,12 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int k) {
 __device__ __forceinline__ uint32_t quad_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // [1,0,3,2]
 __device__ __forceinline__ uint32_t quad_swap2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }  // [2,3,0,1]
 
+// value of lane (pair base + kSrc) to both lanes of a pair (lanes 2q, 2q+1): quad_perm [h,h,2+h,2+h]
+template <int kSrc>
+__device__ __forceinline__ uint32_t pair_bcast(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kSrc ? 0xF5 : 0xA0, 0xF, 0xF, true);
+}
+
 // bases [o, o + 64) of the 128 bases held in (q0..q3), o < 64: two 64-bit chunks
 __device__ __forceinline__ void sm_funnel128(uint64_t q0, uint64_t q1, uint64_t q2, uint64_t q3, uint32_t o, uint64_t& c0,
                                              uint64_t& c1) {

@@ -156,3 +156,50 @@ def test_hits_only_fast_pass_settles_most_reads(world):
         t = ctx.last_timing_ex()
         assert t[3] > 0 and t[4] > 0                      # both passes ran
     ctx.close()
+
+
+def test_reads_with_one_interval_share_a_located_list(world, monkeypatch):
+    """small-RNA batches hold the same molecule many times: reads with the same interval and length are located once
+    and the records of the others point at that list.  Same NH and lists as the oracle, which locates every read;
+    same again with the grouping switched off."""
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 2000, list(range(18, 31)))
+    members = []
+    for f in fam:
+        for a, b in ((0, 30), (0, 18), (0, 19), (5, 27), (12, 30)):   # (0, 18) and (0, 19): intervals may share lo, not hi
+            s = f[a:b]
+            members.append(bytes(b"ACGT"[c] for c in s))
+            members.append(bytes(b"ACGT"[c] for c in (3 - s[::-1])))
+    for rep in range(6):
+        reads += [members[i] for i in rng.permutation(len(members))]
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    packed, lens = sb.pack_reads(reads)
+    lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+    k = np.maximum(nh, 0)
+    oi = (np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))).astype(np.int64)
+
+    def run(ctx):
+        out = []
+        res, hits = ctx.map_batch(packed, lens)
+        out.append((res, hits, ctx.last_stats_ex()))
+        for mode in (0, sb.MAP_HITS_ONLY):
+            rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=mode)
+            res, hits = sb.compact_expand(rec, lists, wide)
+            out.append((res, hits, ctx.last_stats_ex()))
+        for res, hits, stats in out:
+            np.testing.assert_array_equal(res["nh"], nh)
+            gi = (np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))).astype(np.int64)
+            assert np.array_equal(hits[gi], ohits[oi])
+        return [s for _, _, s in out]
+
+    ctx = sb.Context(ix, len(reads))
+    stats = run(ctx)
+    ctx.close()
+    multi = int((nh > 1).sum())
+    for s in stats:
+        assert s[8] > multi // 2 and s[8] < s[1]          # most multi-hit reads share a list; the leaders own theirs
+    monkeypatch.setenv("SBWT_NO_SHARED_LISTS", "1")
+    ctx = sb.Context(ix, len(reads))
+    stats = run(ctx)
+    ctx.close()
+    assert all(s[8] == 0 for s in stats)
