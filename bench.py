@@ -532,6 +532,7 @@ def main():
         accesses = int(stats[0])
         streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(n_hits) * 16
     algo_bytes = 128 * accesses + streamed
+    requests = accesses + (streamed - n_reads * out_bytes) / 128.0 + n_reads * out_bytes / 64.0   # (PMC of the same kernel: within 1 %)
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
     all_accesses = int(stats[0])
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
@@ -563,7 +564,12 @@ def main():
                 "index_lines_per_s_G": round(lines_per_s, 2),
                 "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
                                     "table_GB": round(pbytes / 1e9, 1), "by_chains_per_lane": probe, "peak": gather_peak,
-                                    "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3)},
+                                    "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3),
+                                    # the probe issues nothing but random reads; the kernel also streams its records in and
+                                    # out, and those requests share the same memory pipeline: index lines + 128-byte read
+                                    # requests of the streamed input + 64-byte write requests of the output
+                                    "kernel_hbm_requests_per_s_G": round(requests / (dom_ms * 1e-3) / 1e9, 2),
+                                    "kernel_hbm_requests_frac": round(requests / (dom_ms * 1e-3) / 1e9 / gather_peak, 3)},
                 "whole_step": {"device_ms": round(float(np.mean([k[0] for k in kernel_ms])), 3),
                                "index_lines_per_read": round(all_accesses / n_reads, 3),
                                "k_settle_ms": round(settle_ms, 3), "pending_pass_ms": round(pending_ms, 3),
@@ -658,6 +664,8 @@ def main():
             fq_bytes = write_fastq(fq, pk.reshape(n_e, wpr)[:n_f], ln[:n_f], L)
             fbest = None
             for _ in range(2):
+                if os.path.exists(sam):
+                    os.unlink(sam)                 # (dropping the previous run's gigabyte of page cache is not part of the run)
                 t1 = time.perf_counter()
                 st = ix.map_fastq(fq, sam, n_threads=cores)
                 dt = time.perf_counter() - t1
