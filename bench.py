@@ -524,7 +524,7 @@ def main():
     out_bytes = 16 if compact else 48     # per read: one 16-byte record, or a 32-byte record + the 16-byte hit slot
     if settle_ms > 0:
         # hits layout: the dominant kernel is k_settle -- one bucket (one line) per looked-up read, records in, records out
-        dom_kernel, dom_ms = "k_settle", settle_ms
+        dom_kernel, dom_ms = ("k_settle" if (args.layout == "hits" and wpr == 4) else "k_direct"), settle_ms
         accesses = int(stats[6])
         streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(stats[7]) * 4
     else:
@@ -572,7 +572,7 @@ def main():
                                     "kernel_hbm_requests_frac": round(requests / (dom_ms * 1e-3) / 1e9 / gather_peak, 3)},
                 "whole_step": {"device_ms": round(float(np.mean([k[0] for k in kernel_ms])), 3),
                                "index_lines_per_read": round(all_accesses / n_reads, 3),
-                               "k_settle_ms": round(settle_ms, 3), "pending_pass_ms": round(pending_ms, 3),
+                               "fast_pass_ms": round(settle_ms, 3), "pending_pass_ms": round(pending_ms, 3),
                                "reads_left_pending": int(stats[7])},
                 "hash_lookups_per_read": round(stats[4] / n_reads, 4), "hash_hit_rate": round(stats[5] / stats[4], 4) if stats[4] else None,
                 "stored_pmc": stored,
@@ -709,7 +709,7 @@ def main():
                    "reads_without_sa_interval": n_no_sa, "reads_to_multi_hit_locate": int(stats[1]),
                    "reads_sharing_a_located_list": int(stats[8]) if len(stats) > 8 else 0, "reads_to_depth_first_locate": int(stats[3]),
                    "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
-                   "k_settle_ms": round(float(np.mean([k[3] for k in kernel_ms])), 3),
+                   "fast_pass_ms": round(float(np.mean([k[3] for k in kernel_ms])), 3),
                    "pending_pass_ms": round(float(np.mean([k[4] for k in kernel_ms])), 3),
                    "setup_s": {"genome": round(t_genome, 1), "index_build": round(t_index, 1), "reads": round(t_reads, 1)},
                    "parity_vs_oracle": parity, "origin_check": origin},

@@ -25,6 +25,7 @@
 #include "search_machine.h"
 #include "multi_locate.h"
 #include "settle.h"
+#include "direct.h"
 
 namespace sbwt {
 
@@ -203,7 +204,7 @@ struct sbwt_ctx : MapWork {
   sbwt_compact_result* d_pend_out = nullptr;
   uint64_t pend_words = 0, pend_lens_cap = 0, pend_out_cap = 0;
   hipEvent_t ev_s[2] = {nullptr, nullptr};
-  uint32_t grid_settle = 0;
+  uint32_t grid_settle = 0, grid_direct = 0;
   float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
 };
 
@@ -263,6 +264,10 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, ix->device);
     if (e == hipSuccess) c->grid_settle = (uint32_t)(prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1));
+    int per_cu_d = 0;
+    if (e == hipSuccess)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
+    if (e == hipSuccess) c->grid_direct = (uint32_t)(prop.multiProcessorCount * (per_cu_d > 0 ? per_cu_d : 1));
   }
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
   c->multi_lanes = 256u * 1024u;
@@ -560,9 +565,12 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
                             int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits, uint64_t hits_cap,
                             uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate) {
   const DeviceIndex& d = c->ix->d;
-  const bool settle = (mode & SBWT_MAP_HITS_ONLY) && d.hash_text && d.hash_order && words_per_read == 4 && c->d_pend_list &&
-                      !getenv("SBWT_NO_SETTLE");
-  if (!settle) {
+  // the fast passes need the text-carrying hash table; k_settle (one access) where the caller wants hits only and the
+  // records hold 64 bases, k_direct (two accesses) for the other compact calls with records of 64 or 128 bases
+  const bool fast = d.hash_text && d.hash_order && c->d_pend_list && !getenv("SBWT_NO_SETTLE");
+  const bool settle = fast && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
+  const bool direct = fast && !settle && (words_per_read == 4 || words_per_read == 8) && d.pos_lines && !getenv("SBWT_NO_DIRECT");
+  if (!settle && !direct) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
       c->last_stats[6] = c->last_stats[7] = 0;
@@ -584,10 +592,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.pending_other = &c->d_ctr->pending_other;
   sa.lds_tables = c->sort_lds_bytes ? 1u : 0u;
   sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
+  sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, c->grid_settle);
-  k_settle<<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
+  if (settle) k_settle<<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  else if (words_per_read == 4) k_direct<false><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  else k_direct<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev_s[1], c->stream));
   SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
@@ -604,17 +615,17 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   if (n_pending) {
     if (c->pend_out_cap < n_pending) {  // grown with a quarter to spare, so that batches of similar make-up reuse it
       const uint64_t want = std::min<uint64_t>(c->max_reads, n_pending + (n_pending >> 2));
-      if (int e = ensure(&c->d_pend_packed, &c->pend_words, want * 4)) return e;
+      if (int e = ensure(&c->d_pend_packed, &c->pend_words, want * 8)) return e;  // (records of up to eight words)
       if (int e = ensure(&c->d_pend_lens, &c->pend_lens_cap, want)) return e;
       if (int e = ensure(&c->d_pend_out, &c->pend_out_cap, want)) return e;
     }
-    k_gather_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(d_packed, d_lens, c->d_pend_list, n_pending, c->d_pend_packed,
-                                                                         c->d_pend_lens);
+    k_gather_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(d_packed, d_lens, c->d_pend_list, n_pending, words_per_read / 4,
+                                                                         c->d_pend_packed, c->d_pend_lens);
     SBWT_LAUNCHED();
     const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
     uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, 4, limit, strand, io2,
+    rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
     if (rc != SBWT_OK && rc != SBWT_ERR_CAPACITY) return rc;

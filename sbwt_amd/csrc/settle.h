@@ -36,7 +36,48 @@ struct SettleArgs {
   unsigned long long* pending_other;    // pending reads that were not looked up and missed (long, short run, wide result)
   uint32_t lds_tables;                  // the launch carries (n_chr + 2 n_npos) * 8 bytes of LDS for the filter tables
   uint32_t ring_chr_max;                // chr_id a record holds (test knob, as in SmArgs)
+  uint32_t hits_only;                   // k_direct: SBWT_MAP_HITS_ONLY (a read that differs from the text is settled: no hit)
 };
+
+// The four lanes of a quad look their buckets up together.  Round k: the quad loads the bucket of its lane k, lane
+// `sub` the slot `sub`, in ONE instruction.  A prefix that found its bucket full when the table was built sits in the
+// other bucket of the same 128-byte line (device_index.hip): a second pass looks there for the reads whose first
+// bucket has the tag nowhere and no free slot.  Every lane of the wave calls this (DPP); `look` says who asks.
+// slot / text: the position word and the 32 bases behind the prefix; slot stays ~0 when the prefix is not there.
+__device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4* __restrict__ tab, uint64_t bucket, uint32_t tag,
+                                              uint32_t tmask, bool look, uint32_t sub, uint64_t& slot, uint64_t& text) {
+  bool again = false;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool go = pass == 0 ? look : again;
+    if (!__any(go)) break;
+    const uint64_t bk = pass == 0 ? bucket : (bucket ^ 1ull);
+    uint4 piece[4];
+    uint32_t want[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t b_lo = quad_bcast((uint32_t)bk, k), b_hi = quad_bcast((uint32_t)(bk >> 32), k);
+      want[k] = quad_bcast(go ? 1u : 0u, k);
+      piece[k] = make_uint4(~0u, ~0u, 0, 0);
+      if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t tag_k = quad_bcast(tag, k);
+      const bool used = piece[k].y != 0xFFFFFFFFu;
+      const bool hit = want[k] && used && ((piece[k].x ^ tag_k) & tmask) == 0;
+      // at most one slot of the two buckets carries the tag: OR the (masked) slot over the quad
+      uint32_t v0 = hit ? piece[k].x : 0u, v1 = hit ? piece[k].y : 0u, v2 = hit ? piece[k].z : 0u, v3 = hit ? piece[k].w : 0u;
+      uint32_t any = (hit ? 1u : 0u) | (used ? 0u : 2u);  // bit 0: found; bit 1: a free slot (nothing was ever displaced)
+      v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); v2 |= quad_swap1(v2); v3 |= quad_swap1(v3); any |= quad_swap1(any);
+      v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
+      if (sub == (uint32_t)k && go) {
+        if (any & 1u) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
+        again = pass == 0 && any == 0u && ix.hash_buddy;
+      }
+    }
+  }
+}
 
 constexpr uint32_t kSettleBuf = 512;  // pending indices a wave holds in LDS before it reserves list slots for them
 
@@ -111,41 +152,8 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
     if (look) ++looked;
-    // round k: the quad loads the bucket of its lane k, lane `sub` the slot `sub`.  A prefix that found its bucket
-    // full when the table was built sits in the other bucket of the same 128-byte line (device_index.hip): a
-    // second pass looks there for the reads whose first bucket has the tag nowhere and no free slot.
     uint64_t slot = ~0ull, text = 0;
-    bool again = false;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      const bool go = pass == 0 ? look : again;
-      if (!__any(go)) break;
-      const uint64_t bk = pass == 0 ? bucket : (bucket ^ 1ull);
-      uint4 piece[4];
-      uint32_t want[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t b_lo = quad_bcast((uint32_t)bk, k), b_hi = quad_bcast((uint32_t)(bk >> 32), k);
-        want[k] = quad_bcast(go ? 1u : 0u, k);
-        piece[k] = make_uint4(~0u, ~0u, 0, 0);
-        if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t tag_k = quad_bcast(tag, k);
-        const bool used = piece[k].y != 0xFFFFFFFFu;
-        const bool hit = want[k] && used && ((piece[k].x ^ tag_k) & tmask) == 0;
-        // at most one slot of the two buckets carries the tag: OR the (masked) slot over the quad
-        uint32_t v0 = hit ? piece[k].x : 0u, v1 = hit ? piece[k].y : 0u, v2 = hit ? piece[k].z : 0u, v3 = hit ? piece[k].w : 0u;
-        uint32_t any = (hit ? 1u : 0u) | (used ? 0u : 2u);  // bit 0: found; bit 1: a free slot (nothing was ever displaced)
-        v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); v2 |= quad_swap1(v2); v3 |= quad_swap1(v3); any |= quad_swap1(any);
-        v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
-        if (sub == (uint32_t)k && go) {
-          if (any & 1u) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
-          again = pass == 0 && any == 0u && ix.hash_buddy;
-        }
-      }
-    }
+    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text);
     bool missed = false;  // looked up and not in the table: the general kernels need not look again
     if (look) {
       missed = slot == ~0ull;
@@ -208,14 +216,15 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
   if (lane == 0 && other_n) atomicAdd(a.pending_other, (unsigned long long)other_n);
 }
 
-// the pending reads as a dense batch: record and length of read list[i] at slot i
+// the pending reads as a dense batch: record (`pieces` 16-byte pieces) and length of read list[i] at slot i
 __global__ __launch_bounds__(256) void k_gather_pending(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ lens,
-                                                        const uint32_t* __restrict__ list, uint64_t n_pending,
+                                                        const uint32_t* __restrict__ list, uint64_t n_pending, uint32_t pieces,
                                                         uint32_t* __restrict__ packed2, uint32_t* __restrict__ lens2) {
   const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pending) return;
   const uint32_t r = list[i];
-  reinterpret_cast<uint4*>(packed2)[i] = reinterpret_cast<const uint4*>(packed)[r];
+  for (uint32_t k = 0; k < pieces; ++k)
+    reinterpret_cast<uint4*>(packed2)[i * pieces + k] = reinterpret_cast<const uint4*>(packed)[(uint64_t)r * pieces + k];
   lens2[i] = lens[r];
 }
 

@@ -203,3 +203,47 @@ def test_reads_with_one_interval_share_a_located_list(world, monkeypatch):
     stats = run(ctx)
     ctx.close()
     assert all(s[8] == 0 for s in stats)
+
+
+@pytest.mark.parametrize("lens_", [[32, 36, 50, 51, 52, 53, 60, 64], [65, 80, 100, 101, 120, 128]])
+def test_two_access_fast_pass_reports_intervals(world, monkeypatch, lens_):
+    """compact records WITH SA intervals, and records of up to 128 bases: k_direct answers the reads whose located
+    prefix and PosLine settle them (bucket + one line each) and leaves the rest to the general kernels; every record
+    equals the oracle's, interval included -- and equals what the general kernels alone produce"""
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 20000, lens_, mutate=0.3)
+    for f in fam[:8]:
+        reads.append(bytes(b"ACGT"[c] for c in f) * 2)      # 60 bases, multi-hit prefix
+    packed, lens = sb.pack_reads(reads)
+    for limit, strand, mode in ((1000, 2, 0), (0, 2, 0), (1000, 0, 0), (1000, 1, 0), (1000, 2, sb.MAP_HITS_ONLY)):
+        lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand, nthreads=8)
+        outs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SBWT_NO_DIRECT", "1")
+            else:
+                monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
+            ctx = sb.Context(ix, len(reads))
+            rec, lists, wide = ctx.map_batch_compact(packed, lens, limit=limit, strand=strand, mode=mode)
+            t, st = ctx.last_timing_ex(), ctx.last_stats_ex()
+            ctx.close()
+            ran_direct = not (mode == sb.MAP_HITS_ONLY and max(lens_) <= 64) and not off   # (hits only, short records: k_settle)
+            if ran_direct:
+                assert t[3] > 0 and st[7] < 0.5 * len(reads)   # the fast pass ran and settled most reads
+            if off and mode == 0:
+                assert t[3] == 0
+            meta = (rec["w1"] >> np.uint64(56)).astype(np.uint32)
+            no_sa = (meta & sb.CR_NO_SA) != 0
+            if mode == 0:
+                assert not no_sa.any()
+            res, hits = sb.compact_expand(rec, lists, wide)
+            np.testing.assert_array_equal(res["nh"], nh)
+            np.testing.assert_array_equal(res["sa_lo"][~no_sa], lo[~no_sa])
+            np.testing.assert_array_equal(res["sa_hi"][~no_sa], hi[~no_sa])
+            k = np.maximum(nh, 0)
+            gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+            outs.append((res, no_sa))
+        np.testing.assert_array_equal(outs[0][0]["flags"], outs[1][0]["flags"])
+    monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
