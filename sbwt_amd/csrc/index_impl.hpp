@@ -65,7 +65,7 @@ struct RawDeviceTables {
 
 // launch shapes of the mapping kernels for an index on its device (map_kernels.hip: plan_launches)
 struct sbwt_launch_plan {
-  uint32_t grid_sm_lds = 0, grid_sm_glb = 0, grid_sort = 0;
+  uint32_t grid_sm_lds = 0, grid_sm_glb = 0, grid_sort = 0, grid_bfs = 0;
   size_t sm_lds_bytes = 0, sm_ring_bytes = 0, sort_lds_bytes = 0;
 };
 

@@ -41,6 +41,7 @@ struct Counters {
   unsigned long long pending_count;   // k_settle: reads left to the general kernels
   unsigned long long pending_other;   // ... of which not because their prefix is missing from hash_tab
   unsigned long long shared_count;    // multi-hit reads whose record points at the list of another read with the same interval (k_multi_share)
+  unsigned long long bfs_count;       // reads of the depth-first queue located level by level (k_multi_bfs); the rest took k_multi
 };
 
 struct MapArgs {
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
   Frame* stack = stacks + (uint64_t)lane_global * ix.interval;  // frames 1 .. interval-1
   for (uint64_t q = lane_global; q < qn; q += lanes_total) {
     const uint32_t r = queue[q];
+    if (r == kQueueDone) continue;  // k_multi_bfs took it
     const MultiRead res = rio_load(a.io, r);
     const uint64_t lo = res.lo, hi = res.hi;
     MultiState S;
@@ -162,7 +164,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 9;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 10;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -175,7 +177,7 @@ struct MapWork {
   Frame* d_stacks = nullptr;        // multi_lanes * interval frames
   uint32_t multi_lanes = 0;
   uint32_t grid_sm_lds = 0, grid_sm_glb = 0;  // resident workgroups of k_search_sm
-  uint32_t grid_sort = 0;                     // ... of k_multi_sort
+  uint32_t grid_sort = 0, grid_bfs = 0;       // ... of k_multi_sort, k_multi_bfs
   size_t sm_lds_bytes = 0;                    // 0: the filter tables / sb_abs do not fit the LDS budget
   size_t sm_ring_bytes = 0;                   // result ring of k_search_sm, always in LDS
   size_t sort_lds_bytes = 0;                  // filter tables of k_multi_sort in LDS (0: they stay in global memory)
@@ -191,7 +193,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -229,6 +231,10 @@ static hipError_t plan_launches(const sbwt_index* ix, MapWork* w) {
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, w->sort_lds_bytes);
   if (e != hipSuccess) return e;
   w->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
+  int bfs_per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bfs_per_cu, k_multi_bfs<256, 512>, 256, w->sort_lds_bytes);
+  if (e != hipSuccess) return e;
+  w->grid_bfs = (uint32_t)(prop.multiProcessorCount * (bfs_per_cu > 0 ? bfs_per_cu : 1));
   w->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
   w->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
   return hipSuccess;
@@ -477,6 +483,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     ms.dfs_count = &w.d_ctr->dfs_count;
     ms.lds_tables = w.sort_lds_bytes ? 1u : 0u;
     ms.shared_count = &w.d_ctr->shared_count;
+    ms.bfs_count = &w.d_ctr->bfs_count;
     ms.grp.keys = nullptr;
     ms.grp.leader = nullptr;
     ms.grp.mask = 0;
@@ -495,6 +502,12 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     k_multi_sort<64><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
     k_multi_sort<256><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
     SBWT_LAUNCHED();
+    if (!getenv("SBWT_NO_BFS")) {  // the same walk level by level, a team per read (multi_locate.h); k_multi takes what is left
+      k_multi_bfs<64, 64><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
+      k_multi_bfs<256, 512><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
+      k_multi_bfs<256, 1024><<<w.grid_bfs / 2, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);  // frontiers the second outgrew
+      SBWT_LAUNCHED();
+    }
     k_multi<<<w.multi_lanes / 256, 256, 0, w.stream>>>(d, a, w.d_stacks, w.multi_lanes, w.d_dfs_queue, &w.d_ctr->dfs_count);
     SBWT_LAUNCHED();
     if (w.group_slots) {
@@ -535,6 +548,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     stats_out[4] = (accumulate ? stats_out[4] : 0) + w.h_ctr->hash_stats[0];
     stats_out[5] = (accumulate ? stats_out[5] : 0) + w.h_ctr->hash_stats[1];
     stats_out[8] = (accumulate ? stats_out[8] : 0) + w.h_ctr->shared_count;
+    stats_out[9] = (accumulate ? stats_out[9] : 0) + w.h_ctr->bfs_count;
   }
   *multi_used = w.h_ctr->hit_count;
   if (wide_used) *wide_used = w.h_ctr->wide_count;
@@ -624,7 +638,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     SBWT_LAUNCHED();
     const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
@@ -635,13 +649,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8]};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9]};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }
@@ -850,6 +864,7 @@ int sbwt::finish_index(sbwt_index* ix) {
   ix->plan.grid_sm_lds = w.grid_sm_lds;
   ix->plan.grid_sm_glb = w.grid_sm_glb;
   ix->plan.grid_sort = w.grid_sort;
+  ix->plan.grid_bfs = w.grid_bfs;
   ix->plan.sm_lds_bytes = w.sm_lds_bytes;
   ix->plan.sm_ring_bytes = w.sm_ring_bytes;
   ix->plan.sort_lds_bytes = w.sort_lds_bytes;
@@ -907,6 +922,7 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
   w.grid_sm_lds = ix->plan.grid_sm_lds;
   w.grid_sm_glb = ix->plan.grid_sm_glb;
   w.grid_sort = ix->plan.grid_sort;
+  w.grid_bfs = ix->plan.grid_bfs;
   w.sm_lds_bytes = ix->plan.sm_lds_bytes;
   w.sm_ring_bytes = ix->plan.sm_ring_bytes;
   w.sort_lds_bytes = ix->plan.sort_lds_bytes;

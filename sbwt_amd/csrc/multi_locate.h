@@ -91,6 +91,7 @@ struct MultiSortArgs {
   unsigned long long* dfs_count;
   GroupArgs grp;
   unsigned long long* shared_count;      // reads whose record points at their leader's list (k_multi_share)
+  unsigned long long* bfs_count;         // reads of the depth-first queue that k_multi_bfs located
 };
 
 // Turns the per-wave totals of k_search_sm into global offsets: exclusive prefix sums of the hit slots and of the
@@ -277,6 +278,425 @@ __device__ __forceinline__ void team_bitonic(uint64_t (&v)[4], uint32_t tid, uin
 // pos0 (40 bits) | chr_id << 40 (16 bits) | is_rc << 56 | passed the filters << 57 | t << 58 (6 bits)
 constexpr uint64_t kPayOk = 1ull << 57;
 
+// What the sort of one read's rows works on (LDS of the team): the full keys k0 | k1 (prepended bases, first base most
+// significant, zero padded) and pay (t in the top six bits) of rows 0 .. m-1, padding rows m .. N-1 all ones, the sort
+// words key[i] = (k0[i] & ~0xFFFF) | i, two order buffers and the reduction scratch of the workgroup.
+struct SortLds {
+  uint64_t *k0, *k1, *key, *pay;
+  uint16_t *ord_a, *ord_b;
+  uint64_t (*red)[5];
+  uint32_t* scan;
+};
+
+// Puts the rows of one read in emission order: full key (k0, k1, t) ascending, ties in row order.  or0 .. andt: OR and
+// AND of the key words over the calling thread's rows.  Returns the order as ord[k] = row at place k (k < m), or null
+// when it is key[k] & 0xFFFF.  Every thread of the team calls it.
+template <int T>
+__device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint32_t m, uint32_t N, uint32_t tid, uint32_t lane,
+                                                          uint64_t or0, uint64_t and0, uint64_t or1, uint64_t and1, uint32_t ort,
+                                                          uint32_t andt, bool& used_radix) {
+  constexpr uint32_t kCap = kSortMax / (256 / T);
+  constexpr uint32_t kWaveRows = kCap / 64;  // 64-row groups of a team's rows: the unit the radix passes rank in
+  uint64_t* const k0 = S.k0;
+  uint64_t* const k1 = S.k1;
+  uint64_t* const key = S.key;
+  uint64_t* const pay = S.pay;
+  uint16_t* const ord_a = S.ord_a;
+  uint16_t* const ord_b = S.ord_b;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  // full order of two rows given their offsets: prepended string (zero padded), its length, the offset
+  auto row_less = [&](uint32_t ia, uint32_t ib) -> bool {
+    // all six words first: one LDS round trip instead of three
+    const uint64_t a0 = k0[ia], b0 = k0[ib], a1 = k1[ia], b1 = k1[ib];
+    const uint32_t ta = (uint32_t)(pay[ia] >> 58), tb = (uint32_t)(pay[ib] >> 58);
+    if (a0 != b0) return a0 < b0;
+    if (a1 != b1) return a1 < b1;
+    if (ta != tb) return ta < tb;
+    return ia < ib;
+  };
+  // Which 8-bit digits of the full key -- k0 | k1 | t, 17 digits -- differ between the rows of this read?  The
+  // emission order is the order of the full keys with ties in row order, i.e. what a STABLE sort by those digits
+  // alone gives.  Copies of a repeat share most of their left context (the repeat itself), so few digits
+  // differ: one stable counting pass per differing digit, least significant first, instead of a comparison
+  // sort whose every comparison of two such rows has to go through the full keys.
+  bool radix;
+  uint32_t dmask = 0;  // bit d: digit d differs (0 = the first four bases ... 15 = bases 60..63, 16 = t)
+  {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      or0 |= shfl_xor64(or0, (uint32_t)d); and0 &= shfl_xor64(and0, (uint32_t)d);
+      or1 |= shfl_xor64(or1, (uint32_t)d); and1 &= shfl_xor64(and1, (uint32_t)d);
+      ort |= (uint32_t)__shfl_xor((int)ort, d); andt &= (uint32_t)__shfl_xor((int)andt, d);
+    }
+    if (T == 256) {
+      uint64_t* red = S.red[threadIdx.x >> 6];
+      if (lane == 0) { red[0] = or0; red[1] = and0; red[2] = or1; red[3] = and1; red[4] = u64_of(ort, andt); }
+      __syncthreads();
+      for (uint32_t v = 0; v < 4; ++v) {
+        or0 |= S.red[v][0]; and0 &= S.red[v][1]; or1 |= S.red[v][2]; and1 &= S.red[v][3];
+        ort |= (uint32_t)S.red[v][4]; andt &= (uint32_t)(S.red[v][4] >> 32);
+      }
+    }
+    const uint64_t v0 = or0 & ~and0, v1 = or1 & ~and1;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if ((v0 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << b;
+      if ((v1 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << (8 + b);
+    }
+    if (ort & ~andt) dmask |= 1u << 16;
+    dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)dmask);
+    radix = __popc(dmask) <= (int)kRadixMaxPasses;
+  }
+  const uint16_t* ord = nullptr;  // radix path: row offsets in emission order
+  used_radix = radix;
+  if (radix) {
+    uint16_t* oin = ord_a;
+    uint16_t* oout = ord_b;
+    for (uint32_t k = tid; k < m; k += T) oin[k] = (uint16_t)k;
+    team_sync<T>();
+    uint16_t* const h16 = reinterpret_cast<uint16_t*>(key);  // [256 digits][kWaveRows]: the sort words are not needed here
+    for (int d = 16; d >= 0; --d) {
+      if (!((dmask >> d) & 1u)) continue;
+      for (uint32_t k = tid; k < kCap * 2u; k += T) reinterpret_cast<uint32_t*>(key)[k] = 0u;
+      team_sync<T>();
+      uint32_t dig[4], rnk[4], idx[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
+        dig[kk] = 0; rnk[kk] = 0; idx[kk] = 0;
+        if (wr * 64u >= m) continue;  // wave-uniform
+        const bool valid = j < m;
+        if (valid) {
+          idx[kk] = oin[j];
+          dig[kk] = d == 16 ? (uint32_t)(pay[idx[kk]] >> 58)
+                            : (uint32_t)((d >= 8 ? k1[idx[kk]] : k0[idx[kk]]) >> (56 - 8 * (d & 7))) & 0xFFu;
+        }
+        // lanes of this 64-row group with the same digit; a row's place among them
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const bool bit = (dig[kk] >> b) & 1u;
+          const uint64_t bal = __ballot(bit);
+          peers &= bit ? bal : ~bal;
+        }
+        rnk[kk] = (uint32_t)__popcll(peers & lane_lt);
+        if (valid && rnk[kk] == 0) h16[dig[kk] * kWaveRows + wr] = (uint16_t)__popcll(peers);
+      }
+      team_sync<T>();
+      {
+        // exclusive prefix sums in (digit, group) order: 16 consecutive counters per thread, then over threads
+        uint4* hq = reinterpret_cast<uint4*>(key) + 2u * tid;
+        uint4 qa = hq[0], qb = hq[1];
+        uint32_t w8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t c_lo = w8[k] & 0xFFFFu, c_hi = w8[k] >> 16;
+          w8[k] = run | ((run + c_lo) << 16);
+          run += c_lo + c_hi;
+        }
+        uint32_t inc = run;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)inc, s);
+          if (lane >= (uint32_t)s) inc += o;
+        }
+        uint32_t base = inc - run;
+        if (T == 256) {
+          const uint32_t wave = threadIdx.x >> 6;
+          if (lane == 63) S.scan[wave] = inc;
+          __syncthreads();
+          for (uint32_t v = 0; v < wave; ++v) base += S.scan[v];
+        }
+        const uint32_t b2 = base | (base << 16);
+        hq[0] = make_uint4(w8[0] + b2, w8[1] + b2, w8[2] + b2, w8[3] + b2);
+        hq[1] = make_uint4(w8[4] + b2, w8[5] + b2, w8[6] + b2, w8[7] + b2);
+      }
+      team_sync<T>();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
+        if (j < m) oout[(uint32_t)h16[dig[kk] * kWaveRows + wr] + rnk[kk]] = (uint16_t)idx[kk];
+      }
+      team_sync<T>();
+      uint16_t* const sw = oin; oin = oout; oout = sw;
+    }
+    ord = oin;
+    N = 0;
+  }
+  if (!radix) {
+  // Rows whose left contexts agree over their whole length (copies of a repeat at the same phase of the
+  // sampling, say) are in emission order as they stand, and every comparison among them would take the
+  // full-key path: one pass finds out whether the words are in order already.
+  {
+    bool in_order = true;
+    for (uint32_t i = tid; i + 1 < N; i += T) {
+      const uint64_t ka = key[i], kb = key[i + 1];
+      bool less = ka < kb;
+      if (((ka ^ kb) >> 16) == 0) less = row_less((uint32_t)ka & 0xFFFFu, (uint32_t)kb & 0xFFFFu);
+      in_order = in_order && less;
+    }
+    const bool wave_ok = __all(in_order);
+    if (T == 256) {
+      if (lane == 0) S.scan[threadIdx.x >> 6] = wave_ok ? 1u : 0u;
+      __syncthreads();
+      in_order = (S.scan[0] & S.scan[1] & S.scan[2] & S.scan[3]) != 0;
+      __syncthreads();
+    } else {
+      in_order = wave_ok;
+    }
+    if (in_order) N = 0;  // nothing to sort
+  }
+  // bitonic sort of the N words in LDS; the full keys are looked up only for words whose first 24 bases agree
+  for (uint32_t size = 2; size <= N; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < (N >> 1); t += T) {
+        const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
+        const uint32_t j = i + stride;
+        const bool up = (i & size) == 0;
+        const uint64_t ka = key[i], kb = key[j];
+        bool b_less = kb < ka;
+        if (((ka ^ kb) >> 16) == 0) b_less = row_less((uint32_t)kb & 0xFFFFu, (uint32_t)ka & 0xFFFFu);
+        if (b_less == up) { key[i] = kb; key[j] = ka; }
+      }
+      team_sync<T>();
+    }
+  }
+  }
+  return ord;
+}
+
+// ---- k_multi_bfs: the depth-first locate of searcher.hpp:424-503, level by level --------------------------------
+//
+// For the reads k_multi_sort hands on (rows in LF-inconsistent regions: an index whose ties beyond sort_len are
+// unordered, as upstream's own builder leaves them).  There the walk cannot be replaced by per-row arithmetic (see the
+// header), but it CAN be run breadth first: the nodes of the walk are the intervals (f, e) reached by prepending a
+// string of bases, a node's children are lf1 of both ends for A, C, G, T, every node scans its rows for sampled ones
+// and pushes them, and a node of one sampled row has no children (searcher.hpp:495).  The frontier of one level is
+// expanded by all threads of a team at once -- one (node, base) per thread -- where the depth-first kernel has ONE lane
+// walk the whole tree.  What the depth-first ORDER decides is restored afterwards:
+//  * the emission order is pre-order, A < C < G < T, rows of one node in row order: the hits are sorted by the string
+//    their node prepended (the same keys k_multi_sort sorts by); hits of one node keep their slot order, which is
+//    row order;
+//  * the early exit (searcher.hpp:464: a child is skipped when the number of accepted hits EQUALS the raw interval
+//    size) compares a count that only grows: once it holds at the entry of a node it holds for every later node, so
+//    the list is cut at the first node boundary (in emission order) where the accepted hits before it equal the
+//    interval size -- and nowhere if the count jumps over that value inside one node;
+//  * pushes beyond the reserved slots set SBWT_RF_TRUNCATED (k_multi, MultiState).
+// Teams are waves for reads of up to 64 rows (four per workgroup), workgroups up to kSortMax rows; a read whose
+// frontier or hits outgrow the team's LDS stays in the queue for k_multi.  A read done here leaves ~0 in its entry.
+constexpr uint32_t kQueueDone = ~0u;
+
+template <int T, uint32_t kNodes>  // kNodes: frontier a team holds
+__global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const DeviceIndex ix, const MultiSortArgs a, uint32_t* __restrict__ queue,
+                                                                        const unsigned long long* __restrict__ queue_count) {
+  constexpr uint32_t kTeams = 256 / T;
+  constexpr uint32_t kCap = kSortMax / kTeams;       // hits a team holds
+  __shared__ __attribute__((aligned(16))) uint64_t s_k0[kSortMax], s_k1[kSortMax], s_key[kSortMax], s_pay[kSortMax];
+  // a node: first row | rows << 40, and the bases prepended so far (first base most significant)
+  __shared__ uint64_t s_nfe[2][kTeams * kNodes], s_n0[2][kTeams * kNodes], s_n1[2][kTeams * kNodes];
+  __shared__ uint16_t s_ord_all[2][kSortMax], s_idx_all[kSortMax], s_acc_all[kSortMax];
+  __shared__ uint64_t s_red_all[4][5];
+  __shared__ uint32_t s_scan_all[4];
+  __shared__ uint32_t s_cnt_all[kTeams][4];  // hits, nodes of the next level, overflow, cut
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
+  if (*a.overflow) return;
+  const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
+  if (a.lds_tables) {
+    uint64_t* s_chr = s_tab;
+    uint64_t* s_nk = s_chr + ix.n_chr;
+    uint64_t* s_nv = s_nk + ix.n_npos;
+    for (uint32_t k = threadIdx.x; k < ix.n_chr; k += blockDim.x) s_chr[k] = ix.chr_start[k];
+    for (uint32_t k = threadIdx.x; k < ix.n_npos; k += blockDim.x) { s_nk[k] = ix.npos_key[k]; s_nv[k] = ix.npos_val[k]; }
+    __syncthreads();
+    t_chr = s_chr; t_nk = s_nk; t_nv = s_nv;
+  }
+  const uint32_t team = threadIdx.x / T, tid = threadIdx.x % T, lane = threadIdx.x & 63;
+  uint64_t* k0 = s_k0 + team * kCap;
+  uint64_t* k1 = s_k1 + team * kCap;
+  uint64_t* key = s_key + team * kCap;
+  uint64_t* pay = s_pay + team * kCap;
+  uint16_t* idx_of = s_idx_all + team * kCap;
+  uint16_t* acc_of = s_acc_all + team * kCap;
+  uint32_t* cnt = s_cnt_all[team];
+  const SortLds sort_lds{k0, k1, key, pay, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, s_red_all, s_scan_all};
+  if (ix.interval > 64 || ix.n_chr > 0xFFFFu) return;  // key / payload fields too narrow: k_multi
+  const uint64_t qn = *queue_count;
+
+  // sampled rows among [f, e)
+  auto count_sampled = [&](uint64_t f, uint64_t e) -> uint32_t {
+    const uint64_t bf = f >> 6, be = (e - 1) >> 6;
+    uint32_t n = 0;
+    for (uint64_t bb = bf; bb <= be; ++bb) {
+      const uint32_t o_lo = bb == bf ? (uint32_t)(f & 63) : 0u;
+      const uint32_t o_hi = bb == be ? (uint32_t)((e - 1) & 63) + 1u : 64u;
+      n += (uint32_t)__popcll(ix.blocks1[bb].sampled & below(o_hi) & ~below(o_lo));
+    }
+    return n;
+  };
+  // rows [f, e) of one node at depth `depth`, reached by prepending the bases in (p0, p1), n > 0 of them sampled:
+  // push those (scan_sampled + multi_push of map_kernels.hip).  Returns true for a node of one (sampled) row.
+  auto emit_node = [&](uint64_t f, uint64_t e, uint32_t depth, uint64_t p0, uint64_t p1, uint32_t L, uint32_t n) -> bool {
+    const uint64_t bf = f >> 6, be = (e - 1) >> 6;
+    uint32_t at = atomicAdd(&cnt[0], n);
+    if (at + n > kCap) { cnt[2] = 1u; return false; }
+    for (uint64_t bb = bf; bb <= be; ++bb) {
+      const Block1* b = ix.blocks1 + bb;
+      const uint64_t sampled = b->sampled, sbase = b->sampled_base;
+      const uint32_t o_lo = bb == bf ? (uint32_t)(f & 63) : 0u;
+      const uint32_t o_hi = bb == be ? (uint32_t)((e - 1) & 63) + 1u : 64u;
+      uint64_t bits = sampled & below(o_hi) & ~below(o_lo);
+      while (bits) {
+        const uint32_t o = (uint32_t)__ffsll((unsigned long long)bits) - 1u;
+        bits &= bits - 1;
+        const uint64_t sa = ix.loc_vals[sbase + (uint64_t)__popcll(sampled & below(o))];
+        sbwt_hit h;
+        uint64_t py = (uint64_t)depth << 58;
+        if (push_position_keys(ix, t_chr, t_nk, t_nv, (uint64_t)depth + sa, L, a.strand, &h)) {
+          if (h.pos0 > kPosMask) cnt[2] = 1u;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
+          py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+        }
+        k0[at] = p0; k1[at] = p1; pay[at] = py;
+        ++at;
+      }
+    }
+    return e - f == 1;
+  };
+
+  for (uint64_t q = (uint64_t)blockIdx.x * kTeams + team; q < qn; q += (uint64_t)gridDim.x * kTeams) {
+    const uint32_t r = queue[q];
+    if (r == kQueueDone) continue;  // (team-uniform)
+    const MultiRead res = rio_load(a.io, r);  // first_hit is global by now (k_multi_sort)
+    const uint64_t lo = res.lo, m = res.hi - res.lo;
+    if (m > (T == 64 ? kNodes : kSortMax)) continue;
+    const uint32_t L = a.lens[r];
+    team_sync<T>();  // the previous read is done with the team's LDS
+    if (tid < 4) cnt[tid] = 0;
+    team_sync<T>();
+    if (tid == 0) {
+      const uint32_t n0 = count_sampled(lo, res.hi);
+      if (n0) emit_node(lo, res.hi, 0, 0, 0, L, n0);  // level 0 (searcher.hpp:424-443): no early return there
+      s_nfe[0][team * kNodes] = lo | (m << kPosBits); s_n0[0][team * kNodes] = 0; s_n1[0][team * kNodes] = 0;
+    }
+    team_sync<T>();
+    uint32_t n_cur = 1, cur = 0;
+    for (uint32_t d = 1; d < ix.interval && n_cur && !cnt[2]; ++d) {
+      const uint64_t *cfe = s_nfe[cur] + team * kNodes, *c0 = s_n0[cur] + team * kNodes, *c1 = s_n1[cur] + team * kNodes;
+      uint64_t *xfe = s_nfe[cur ^ 1] + team * kNodes, *x0 = s_n0[cur ^ 1] + team * kNodes, *x1 = s_n1[cur ^ 1] + team * kNodes;
+      // four (node, base) items per thread at a time, phase by phase: the rank queries of all four are in flight
+      // together, then the sampled-row bitmaps of their children; only the rare pushes run one after the other
+      constexpr int U = 4;
+      for (uint32_t it0 = 0; it0 < 4u * n_cur; it0 += (uint32_t)T * U) {
+        uint64_t nf[U], ne[U];
+        uint32_t ns[U];
+        bool act[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const uint32_t it = it0 + (uint32_t)j * T + tid;
+          act[j] = it < 4u * n_cur;
+          const uint64_t fe = cfe[act[j] ? it >> 2 : 0u];
+          const uint64_t f = fe & kPosMask, e = f + (fe >> kPosBits);
+          nf[j] = lf1(ix, f, it & 3u);
+          ne[j] = lf1(ix, e, it & 3u);
+          act[j] = act[j] && nf[j] < ne[j];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) ns[j] = act[j] ? count_sampled(nf[j], ne[j]) : 0u;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (!act[j]) continue;
+          const uint32_t it = it0 + (uint32_t)j * T + tid, node = it >> 2, c = it & 3u;
+          uint64_t p0 = c0[node], p1 = c1[node];
+          if (d <= 32u) p0 |= (uint64_t)c << (64u - 2u * d); else p1 |= (uint64_t)c << (64u - 2u * (d - 32u));
+          const bool single = ns[j] ? emit_node(nf[j], ne[j], d, p0, p1, L, ns[j]) : false;
+          if (!single && d + 1 < ix.interval) {
+            const uint32_t at = atomicAdd(&cnt[1], 1u);
+            if (at < kNodes) { xfe[at] = nf[j] | ((ne[j] - nf[j]) << kPosBits); x0[at] = p0; x1[at] = p1; } else cnt[2] = 1u;
+          }
+        }
+      }
+      team_sync<T>();
+      n_cur = cnt[1];
+      team_sync<T>();
+      if (tid == 0) cnt[1] = 0;
+      cur ^= 1;
+      team_sync<T>();
+    }
+    if (cnt[2]) continue;  // outgrew the team: the read stays queued for k_multi
+    const uint32_t H = cnt[0];
+    // ---- emission order
+    uint32_t N = 64;
+    while (N < H && N < kCap) N <<= 1;
+    uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
+    uint32_t ort = 0, andt = ~0u;
+    for (uint32_t i = tid; i < N; i += T) {
+      if (i < H) {
+        const uint64_t h0 = k0[i], h1 = k1[i];
+        const uint32_t t = (uint32_t)(pay[i] >> 58);
+        or0 |= h0; and0 &= h0; or1 |= h1; and1 &= h1; ort |= t; andt &= t;
+      } else {
+        k0[i] = ~0ull; k1[i] = ~0ull; pay[i] = 63ull << 58;
+      }
+      key[i] = (k0[i] & ~0xFFFFull) | i;
+    }
+    team_sync<T>();
+    bool radix = false;
+    const uint16_t* ord = team_sort_rows<T>(sort_lds, H, N, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+    // ---- accepted hits before every place, node boundaries, the cut
+    uint32_t base = 0;
+    for (uint32_t c = 0; c < H; c += T) {
+      const uint32_t k = c + tid;
+      uint32_t i = 0;
+      bool ok = false;
+      if (k < H) {
+        i = ord ? (uint32_t)ord[k] : ((uint32_t)key[k] & 0xFFFFu);
+        ok = (pay[i] & kPayOk) != 0;
+        idx_of[k] = (uint16_t)i;
+      }
+      const uint64_t bal = __ballot(ok);
+      uint32_t off = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (T == 256) {
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane == 0) s_scan_all[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        for (uint32_t v = 0; v < wave; ++v) off += s_scan_all[v];
+        base += s_scan_all[0] + s_scan_all[1] + s_scan_all[2] + s_scan_all[3];
+        __syncthreads();
+      } else {
+        base += (uint32_t)__popcll(bal);
+      }
+      if (k < H) acc_of[k] = (uint16_t)off;  // accepted hits before place k
+    }
+    if (tid == 0) cnt[3] = H;
+    team_sync<T>();
+    const uint64_t maybe = (uint64_t)(int64_t)(int32_t)(uint32_t)m;  // (searcher.hpp:412,464: an int against a size_t)
+    for (uint32_t k = tid + 1; k < H; k += T) {
+      const uint32_t ia = idx_of[k - 1], ib = idx_of[k];
+      const bool boundary = k0[ia] != k0[ib] || k1[ia] != k1[ib] || (pay[ia] >> 58) != (pay[ib] >> 58);
+      if (boundary && (uint64_t)acc_of[k] == maybe) atomicMin(&cnt[3], k);
+    }
+    team_sync<T>();
+    const uint32_t cut = cnt[3];
+    const uint32_t nres = cut < H ? (uint32_t)acc_of[cut] : base;
+    sbwt_hit* out = a.hits + res.first_hit;
+    for (uint32_t k = tid; k < cut; k += T) {
+      const uint64_t py = pay[idx_of[k]];
+      if ((py & kPayOk) && (uint64_t)acc_of[k] < m) {
+        sbwt_hit h;
+        h.pos0 = py & kPosMask;
+        h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
+        h.is_rc = (uint32_t)(py >> 56) & 1u;
+        out[acc_of[k]] = h;
+      }
+    }
+    if (tid == 0) {
+      rio_store_multi(a.io, r, res.first_hit, true, (int32_t)((uint64_t)nres < m ? nres : (uint32_t)m), (uint64_t)nres > m ? SBWT_RF_TRUNCATED : 0u);
+      queue[q] = kQueueDone;
+      atomicAdd(a.bfs_count, 1ull);
+    }
+  }
+}
+
 // -DSBWT_PHASE_CLOCKS: thread 0 of every team adds the clocks each phase of a read took to g_multi_phase[] (a
 // development aid; map_pass prints the totals)
 #ifdef SBWT_PHASE_CLOCKS
@@ -329,20 +749,9 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   uint32_t* s_bad = s_bad_all + team;
   uint16_t* ord_a = s_ord_all[0] + team * kCap;
   uint16_t* ord_b = s_ord_all[1] + team * kCap;
-  constexpr uint32_t kWaveRows = kCap / 64;  // 64-row groups of a team's rows: the unit the radix passes rank in
-  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  const SortLds sort_lds{k0, k1, key, pay, ord_a, ord_b, s_red_all, s_scan_all};
   const uint64_t m_text = ix.n - 1;
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
-  // full order of two rows given their offsets: prepended string (zero padded), its length, the offset
-  auto row_less = [&](uint32_t ia, uint32_t ib) -> bool {
-    // all six words first: one LDS round trip instead of three
-    const uint64_t a0 = k0[ia], b0 = k0[ib], a1 = k1[ia], b1 = k1[ib];
-    const uint32_t ta = (uint32_t)(pay[ia] >> 58), tb = (uint32_t)(pay[ib] >> 58);
-    if (a0 != b0) return a0 < b0;
-    if (a1 != b1) return a1 < b1;
-    if (ta != tb) return ta < tb;
-    return ia < ib;
-  };
   // teams stride over the waves of the search kernel; each wave queued its reads at queue[w * chunk ..)
   for (uint32_t w = blockIdx.x * kTeams + team; w < a.n_waves; w += gridDim.x * kTeams) {
     const WaveInfo wi = a.wave_info[w];
@@ -485,157 +894,9 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
           team_sync<T>();
           continue;
         }
-        // Which 8-bit digits of the full key -- k0 | k1 | t, 17 digits -- differ between the rows of this read?  The
-        // emission order is the order of the full keys with ties in row order, i.e. what a STABLE sort by those digits
-        // alone gives.  Copies of a repeat share most of their left context (the repeat itself), so few digits
-        // differ: one stable counting pass per differing digit, least significant first, instead of a comparison
-        // sort whose every comparison of two such rows has to go through the full keys.
-        bool radix;
-        uint32_t dmask = 0;  // bit d: digit d differs (0 = the first four bases ... 15 = bases 60..63, 16 = t)
-        {
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) {
-            or0 |= shfl_xor64(or0, (uint32_t)d); and0 &= shfl_xor64(and0, (uint32_t)d);
-            or1 |= shfl_xor64(or1, (uint32_t)d); and1 &= shfl_xor64(and1, (uint32_t)d);
-            ort |= (uint32_t)__shfl_xor((int)ort, d); andt &= (uint32_t)__shfl_xor((int)andt, d);
-          }
-          if (T == 256) {
-            uint64_t* red = s_red_all[threadIdx.x >> 6];
-            if (lane == 0) { red[0] = or0; red[1] = and0; red[2] = or1; red[3] = and1; red[4] = u64_of(ort, andt); }
-            __syncthreads();
-            for (uint32_t v = 0; v < 4; ++v) {
-              or0 |= s_red_all[v][0]; and0 &= s_red_all[v][1]; or1 |= s_red_all[v][2]; and1 &= s_red_all[v][3];
-              ort |= (uint32_t)s_red_all[v][4]; andt &= (uint32_t)(s_red_all[v][4] >> 32);
-            }
-          }
-          const uint64_t v0 = or0 & ~and0, v1 = or1 & ~and1;
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            if ((v0 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << b;
-            if ((v1 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << (8 + b);
-          }
-          if (ort & ~andt) dmask |= 1u << 16;
-          dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)dmask);
-          radix = __popc(dmask) <= (int)kRadixMaxPasses;
-        }
-        SBWT_PHASE(5);
-        const uint16_t* ord = nullptr;  // radix path: row offsets in emission order
-        if (radix) {
-          uint16_t* oin = ord_a;
-          uint16_t* oout = ord_b;
-          for (uint32_t k = tid; k < m; k += T) oin[k] = (uint16_t)k;
-          team_sync<T>();
-          uint16_t* const h16 = reinterpret_cast<uint16_t*>(key);  // [256 digits][kWaveRows]: the sort words are not needed here
-          for (int d = 16; d >= 0; --d) {
-            if (!((dmask >> d) & 1u)) continue;
-            for (uint32_t k = tid; k < kCap * 2u; k += T) reinterpret_cast<uint32_t*>(key)[k] = 0u;
-            team_sync<T>();
-            uint32_t dig[4], rnk[4], idx[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
-              dig[kk] = 0; rnk[kk] = 0; idx[kk] = 0;
-              if (wr * 64u >= m) continue;  // wave-uniform
-              const bool valid = j < m;
-              if (valid) {
-                idx[kk] = oin[j];
-                dig[kk] = d == 16 ? (uint32_t)(pay[idx[kk]] >> 58)
-                                  : (uint32_t)((d >= 8 ? k1[idx[kk]] : k0[idx[kk]]) >> (56 - 8 * (d & 7))) & 0xFFu;
-              }
-              // lanes of this 64-row group with the same digit; a row's place among them
-              uint64_t peers = __ballot(valid);
-#pragma unroll
-              for (int b = 0; b < 8; ++b) {
-                const bool bit = (dig[kk] >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-              }
-              rnk[kk] = (uint32_t)__popcll(peers & lane_lt);
-              if (valid && rnk[kk] == 0) h16[dig[kk] * kWaveRows + wr] = (uint16_t)__popcll(peers);
-            }
-            team_sync<T>();
-            {
-              // exclusive prefix sums in (digit, group) order: 16 consecutive counters per thread, then over threads
-              uint4* hq = reinterpret_cast<uint4*>(key) + 2u * tid;
-              uint4 qa = hq[0], qb = hq[1];
-              uint32_t w8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-              uint32_t run = 0;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                const uint32_t c_lo = w8[k] & 0xFFFFu, c_hi = w8[k] >> 16;
-                w8[k] = run | ((run + c_lo) << 16);
-                run += c_lo + c_hi;
-              }
-              uint32_t inc = run;
-#pragma unroll
-              for (int s = 1; s < 64; s <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)inc, s);
-                if (lane >= (uint32_t)s) inc += o;
-              }
-              uint32_t base = inc - run;
-              if (T == 256) {
-                const uint32_t wave = threadIdx.x >> 6;
-                if (lane == 63) s_scan_all[wave] = inc;
-                __syncthreads();
-                for (uint32_t v = 0; v < wave; ++v) base += s_scan_all[v];
-              }
-              const uint32_t b2 = base | (base << 16);
-              hq[0] = make_uint4(w8[0] + b2, w8[1] + b2, w8[2] + b2, w8[3] + b2);
-              hq[1] = make_uint4(w8[4] + b2, w8[5] + b2, w8[6] + b2, w8[7] + b2);
-            }
-            team_sync<T>();
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
-              if (j < m) oout[(uint32_t)h16[dig[kk] * kWaveRows + wr] + rnk[kk]] = (uint16_t)idx[kk];
-            }
-            team_sync<T>();
-            uint16_t* const sw = oin; oin = oout; oout = sw;
-          }
-          ord = oin;
-          N = 0;
-          SBWT_PHASE(6);
-        }
-        if (!radix) {
-        // Rows whose left contexts agree over their whole length (copies of a repeat at the same phase of the
-        // sampling, say) are in emission order as they stand, and every comparison among them would take the
-        // full-key path: one pass finds out whether the words are in order already.
-        {
-          bool in_order = true;
-          for (uint32_t i = tid; i + 1 < N; i += T) {
-            const uint64_t ka = key[i], kb = key[i + 1];
-            bool less = ka < kb;
-            if (((ka ^ kb) >> 16) == 0) less = row_less((uint32_t)ka & 0xFFFFu, (uint32_t)kb & 0xFFFFu);
-            in_order = in_order && less;
-          }
-          const bool wave_ok = __all(in_order);
-          if (T == 256) {
-            if (lane == 0) s_scan_all[threadIdx.x >> 6] = wave_ok ? 1u : 0u;
-            __syncthreads();
-            in_order = (s_scan_all[0] & s_scan_all[1] & s_scan_all[2] & s_scan_all[3]) != 0;
-            __syncthreads();
-          } else {
-            in_order = wave_ok;
-          }
-          if (in_order) N = 0;  // nothing to sort
-        }
-        // bitonic sort of the N words in LDS; the full keys are looked up only for words whose first 24 bases agree
-        for (uint32_t size = 2; size <= N; size <<= 1) {
-          for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < (N >> 1); t += T) {
-              const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
-              const uint32_t j = i + stride;
-              const bool up = (i & size) == 0;
-              const uint64_t ka = key[i], kb = key[j];
-              bool b_less = kb < ka;
-              if (((ka ^ kb) >> 16) == 0) b_less = row_less((uint32_t)kb & 0xFFFFu, (uint32_t)ka & 0xFFFFu);
-              if (b_less == up) { key[i] = kb; key[j] = ka; }
-            }
-            team_sync<T>();
-          }
-        }
-          SBWT_PHASE(7);
-        }
+        bool radix = false;
+        const uint16_t* ord = team_sort_rows<T>(sort_lds, (uint32_t)m, N, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+        SBWT_PHASE(6);
         // rows in emission order: compact those that passed the filters, write
         sbwt_hit* out = a.hits + res.first_hit;
         uint32_t base = 0;

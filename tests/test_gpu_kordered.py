@@ -124,7 +124,26 @@ def test_tie_shuffled_index_matches_oracle(golden_dir, oracle, k, seed):
         a = hits[int(res["first_hit"][r]): int(res["first_hit"][r]) + int(nh[r])]
         assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d" % r
     assert (nh > 0).sum() > len(reads) // 3
-    ctx.close(); ix.close(); oix.close()
+    st = ctx.last_stats_ex()
+    ctx.close()
+    # the reads whose rows lie in LF-inconsistent regions take upstream's walk: level by level (k_multi_bfs) unless
+    # switched off, then depth first (k_multi) -- the same lists either way
+    if k < 1000:
+        assert st[3] > 0 and st[9] == st[3]
+        os.environ["SBWT_NO_BFS"] = "1"
+        try:
+            ctx = sb.Context(ix, len(reads))
+            res2, hits2 = ctx.map_batch(packed, lens)
+            st2 = ctx.last_stats_ex()
+            ctx.close()
+        finally:
+            os.environ.pop("SBWT_NO_BFS")
+        assert st2[3] == st[3] and st2[9] == 0
+        np.testing.assert_array_equal(res2["nh"], nh)
+        for r in np.nonzero(nh)[0]:
+            a = hits2[int(res2["first_hit"][r]): int(res2["first_hit"][r]) + int(nh[r])]
+            assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d (depth first)" % r
+    ix.close(); oix.close()
 
 
 @pytest.mark.parametrize("depth", [27, 54])
