@@ -266,7 +266,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev_s[k]);
   if (e == hipSuccess) {
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_settle, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_settle<true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, ix->device);
     if (e == hipSuccess) c->grid_settle = (uint32_t)(prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1));
@@ -610,7 +610,8 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
-  if (settle) k_settle<<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  else if (settle) k_settle<false><<<grid, 256, 0, c->stream>>>(d, sa);
   else if (words_per_read == 4) k_direct<false><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   else k_direct<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   SBWT_LAUNCHED();

@@ -95,22 +95,15 @@ __device__ __forceinline__ bool step_two_bases(const DeviceIndex& ix, uint32_t t
 // std::map::upper_bound(x) followed by advance(-1) (searcher.hpp:519-533) over a sorted key array
 // whose first key is 0
 __device__ __forceinline__ uint32_t upper_bound_minus1(const uint64_t* __restrict__ keys, uint32_t n, uint64_t x) {
-  uint32_t l = 0, h = n;
-  while (l < h) {
-    uint32_t m = (l + h) >> 1;
-    if (keys[m] <= x) l = m + 1; else h = m;
+  // binary lifting: floor(log2 n) + 1 steps whatever x is, so a wave runs them without diverging
+  uint32_t cnt = 0;  // keys known to be <= x
+  for (uint32_t step = n ? 1u << (31 - __clz((int)n)) : 0u; step; step >>= 1) {
+    const uint32_t c = cnt + step;
+    if (c <= n && keys[c - 1u] <= x) cnt = c;
   }
-  return l - 1;
+  return cnt - 1u;  // keys[0] = 0 <= x: cnt >= 1
 }
 
-// searcher.hpp:504-539 for one lane.  chr / npos_key / npos_val are the sorted tables (global memory or a
-// workgroup's LDS copy).  Upstream takes upper_bound - 1 of the first and of the last base in both maps (:519-533)
-// and drops the hit when the chromosome NAMES differ or the N-free segments differ.  While position + L - 1 does
-// not wrap that is: no key lies in (position, position + L - 1] (chromosome keys between two chromosomes of the
-// same name excepted: chr_class, set only when names repeat).  It wraps for the false candidates the c_functions
-// table carries -- the up to 11 end-of-text suffixes shorter than 12 sit at the end of the preceding 12-mer's
-// bucket, a hit built on one has p + L > 2 * real_size and `position` underflows (unsigned, as
-// upstream's INTTYPE does) -- and then both ends are looked up as upstream does, on the wrapped values.
 // The same for four keys at once, as fixed-length binary lifting: the steps of the four searches interleave, so a
 // step costs one table latency (LDS or cache), not four, and no lane diverges.
 __device__ __forceinline__ void upper_bound_minus1_x4(const uint64_t* __restrict__ keys, uint32_t n, const uint64_t (&x)[4],

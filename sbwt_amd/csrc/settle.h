@@ -81,10 +81,13 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
 
 constexpr uint32_t kSettleBuf = 512;  // pending indices a wave holds in LDS before it reserves list slots for them
 
+// kLds: the filter tables are staged in LDS (the launch carries (n_chr + 2 n_npos) * 8 bytes of it): a compile-time
+// choice, so that their reads are LDS instructions and not flat loads
+template <bool kLds>
 __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const SettleArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
-  if (a.lds_tables) {
+  if (kLds) {
     uint64_t* s_chr = s_tab;
     uint64_t* s_nk = s_chr + ix.n_chr;
     uint64_t* s_nv = s_nk + ix.n_npos;
