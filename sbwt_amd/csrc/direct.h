@@ -29,13 +29,13 @@ namespace sbwt {
 constexpr uint32_t kDirectBuf = 256;  // pending indices a wave holds in LDS before it reserves list slots for them
 
 // a.packed: records of 4 (kLong: 8) words; a.hits_only as SBWT_MAP_HITS_ONLY
-template <bool kLong>
+template <bool kLong, bool kLds>  // kLds: the filter tables are staged in LDS (as in k_settle)
 __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const SettleArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   __shared__ __attribute__((aligned(16))) uint4 s_img_all[4][512];  // per wave: the PosLines of its 64 reads (8 KB)
   __shared__ uint32_t s_pend_all[4][kDirectBuf];
   const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
-  if (a.lds_tables) {
+  if (kLds) {
     uint64_t* s_chr = s_tab;
     uint64_t* s_nk = s_chr + ix.n_chr;
     uint64_t* s_nv = s_nk + ix.n_npos;

@@ -228,7 +228,7 @@ static hipError_t plan_launches(const sbwt_index* ix, MapWork* w) {
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_lds, k_search_sm<true, true>, 256, w->sm_lds_bytes + ring_bytes);
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sm_glb, k_search_sm<false, true>, 256, ring_bytes);
   if (ix->d.n_chr + ix->d.n_npos <= max_keys) w->sort_lds_bytes = ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256>, 256, w->sort_lds_bytes);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&sort_per_cu, k_multi_sort<256, true>, 256, w->sort_lds_bytes);
   if (e != hipSuccess) return e;
   w->grid_sort = (uint32_t)(prop.multiProcessorCount * (sort_per_cu > 0 ? sort_per_cu : 1));
   int bfs_per_cu = 0;
@@ -272,7 +272,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     if (e == hipSuccess) c->grid_settle = (uint32_t)(prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1));
     int per_cu_d = 0;
     if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<true, true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
     if (e == hipSuccess) c->grid_direct = (uint32_t)(prop.multiProcessorCount * (per_cu_d > 0 ? per_cu_d : 1));
   }
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
@@ -499,8 +499,13 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
       k_multi_group<<<n_waves, 256, 0, w.stream>>>(ms);
       SBWT_LAUNCHED();
     }
-    k_multi_sort<64><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
-    k_multi_sort<256><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
+    if (w.sort_lds_bytes) {
+      k_multi_sort<64, true><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
+      k_multi_sort<256, true><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms);
+    } else {
+      k_multi_sort<64, false><<<w.grid_sort, 256, 0, w.stream>>>(d, ms);
+      k_multi_sort<256, false><<<w.grid_sort, 256, 0, w.stream>>>(d, ms);
+    }
     SBWT_LAUNCHED();
     if (!getenv("SBWT_NO_BFS")) {  // the same walk level by level, a team per read (multi_locate.h); k_multi takes what is left
       k_multi_bfs<64, 64><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
@@ -612,8 +617,10 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
   if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   else if (settle) k_settle<false><<<grid, 256, 0, c->stream>>>(d, sa);
-  else if (words_per_read == 4) k_direct<false><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
-  else k_direct<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  else if (words_per_read == 4 && c->sort_lds_bytes) k_direct<false, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  else if (words_per_read == 4) k_direct<false, false><<<grid, 256, 0, c->stream>>>(d, sa);
+  else if (c->sort_lds_bytes) k_direct<true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  else k_direct<true, false><<<grid, 256, 0, c->stream>>>(d, sa);
   SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev_s[1], c->stream));
   SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));

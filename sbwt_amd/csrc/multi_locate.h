@@ -708,7 +708,7 @@ __device__ unsigned long long g_multi_phase[24];  // [0..12) wave teams, [12..24
 #define SBWT_PHASE_MEM(k) do { } while (0)
 #endif
 
-template <int T>
+template <int T, bool kLds>  // kLds: the filter tables are staged in LDS (a compile-time choice: LDS reads, not flat loads)
 __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;  // rows a team can sort
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
   // push_position tables: LDS copies when they fit
   const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
-  if (a.lds_tables) {
+  if (kLds) {
     uint64_t* s_chr = s_tab;
     uint64_t* s_nk = s_chr + ix.n_chr;
     uint64_t* s_nv = s_nk + ix.n_npos;
