@@ -466,6 +466,17 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
   return ord;
 }
 
+// -DSBWT_PHASE_CLOCKS: thread 0 of every team adds the clocks each phase of a read took to g_multi_phase[] (a
+// development aid; map_pass prints the totals)
+#ifdef SBWT_PHASE_CLOCKS
+__device__ unsigned long long g_multi_phase[24];  // [0..12) wave teams, [12..24) workgroup teams
+#define SBWT_PHASE(k) do { const unsigned long long c_ = clock64(); if (tid == 0) s_phase[team][k] += c_ - ph_t; ph_t = c_; } while (0)
+#define SBWT_PHASE_MEM(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SBWT_PHASE(k); } while (0)
+#else
+#define SBWT_PHASE(k) do { } while (0)
+#define SBWT_PHASE_MEM(k) do { } while (0)
+#endif
+
 // ---- k_multi_bfs: the depth-first locate of searcher.hpp:424-503, level by level --------------------------------
 //
 // For the reads k_multi_sort hands on (rows in LF-inconsistent regions: an index whose ties beyond sort_len are
@@ -488,17 +499,26 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
 constexpr uint32_t kQueueDone = ~0u;
 
 template <int T, uint32_t kNodes>  // kNodes: frontier a team holds
-__global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const DeviceIndex ix, const MultiSortArgs a, uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const DeviceIndex ix, const MultiSortArgs a, uint32_t* __restrict__ queue,
                                                                         const unsigned long long* __restrict__ queue_count) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;       // hits a team holds
-  __shared__ __attribute__((aligned(16))) uint64_t s_k0[kSortMax], s_k1[kSortMax], s_key[kSortMax], s_pay[kSortMax];
-  // a node: first row | rows << 40, and the bases prepended so far (first base most significant)
-  __shared__ uint64_t s_nfe[2][kTeams * kNodes], s_n0[2][kTeams * kNodes], s_n1[2][kTeams * kNodes];
-  __shared__ uint16_t s_ord_all[2][kSortMax], s_idx_all[kSortMax], s_acc_all[kSortMax];
+  __shared__ __attribute__((aligned(16))) uint64_t s_k0[kSortMax], s_k1[kSortMax], s_pay[kSortMax];
+  // Per team, one region used twice: while the walk runs, the two frontiers -- a node is its first row | rows << 40 and
+  // the bases prepended so far (first base most significant) --; once it is over, what the sort and the cut need
+  // (sort words, two order buffers, the row at every place, accepted hits before every place).  The kernel is bound by
+  // the latency of 63 dependent levels per read: LDS per team decides how many reads a CU has in flight.
+  constexpr uint32_t kFrontierBytes = 2u * 3u * kNodes * 8u, kSortBytes = kCap * (8u + 4u * 2u);
+  constexpr uint32_t kRawTeam = kFrontierBytes > kSortBytes ? kFrontierBytes : kSortBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTeams * kRawTeam];
   __shared__ uint64_t s_red_all[4][5];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_cnt_all[kTeams][4];  // hits, nodes of the next level, overflow, cut
+  // workgroup teams: children of more than kBigRows rows are scanned by a whole wave (a lane per 64-row block), not by
+  // the thread that made them -- on tie-shuffled tables the copies of a repeat stay in ONE node level after level
+  constexpr uint32_t kBigRows = 128, kBigMax = 16;
+  __shared__ uint64_t s_big[kBigMax][4];     // first row, end row, prepended bases
+  __shared__ uint32_t s_nbig;
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   if (*a.overflow) return;
   const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
@@ -514,14 +534,23 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const D
   const uint32_t team = threadIdx.x / T, tid = threadIdx.x % T, lane = threadIdx.x & 63;
   uint64_t* k0 = s_k0 + team * kCap;
   uint64_t* k1 = s_k1 + team * kCap;
-  uint64_t* key = s_key + team * kCap;
+  unsigned char* const raw = s_raw + team * kRawTeam;
+  uint64_t* const fr = reinterpret_cast<uint64_t*>(raw);  // [2][3][kNodes]
+  uint64_t* key = reinterpret_cast<uint64_t*>(raw);
+  uint16_t* const ord0 = reinterpret_cast<uint16_t*>(raw + kCap * 8u);
   uint64_t* pay = s_pay + team * kCap;
-  uint16_t* idx_of = s_idx_all + team * kCap;
-  uint16_t* acc_of = s_acc_all + team * kCap;
+  uint16_t* idx_of = ord0 + 2u * kCap;
+  uint16_t* acc_of = ord0 + 3u * kCap;
   uint32_t* cnt = s_cnt_all[team];
-  const SortLds sort_lds{k0, k1, key, pay, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, s_red_all, s_scan_all};
+  const SortLds sort_lds{k0, k1, key, pay, ord0, ord0 + kCap, s_red_all, s_scan_all};
   if (ix.interval > 64 || ix.n_chr > 0xFFFFu) return;  // key / payload fields too narrow: k_multi
   const uint64_t qn = *queue_count;
+#ifdef SBWT_PHASE_CLOCKS
+  __shared__ unsigned long long s_phase[4][12];
+  if (tid < 12) s_phase[team][tid] = 0;
+  team_sync<T>();
+  unsigned long long ph_t = clock64();
+#endif
 
   // sampled rows among [f, e)
   auto count_sampled = [&](uint64_t f, uint64_t e) -> uint32_t {
@@ -572,17 +601,19 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const D
     const uint32_t L = a.lens[r];
     team_sync<T>();  // the previous read is done with the team's LDS
     if (tid < 4) cnt[tid] = 0;
+    if (T == 256 && tid == 0) s_nbig = 0;
     team_sync<T>();
     if (tid == 0) {
       const uint32_t n0 = count_sampled(lo, res.hi);
       if (n0) emit_node(lo, res.hi, 0, 0, 0, L, n0);  // level 0 (searcher.hpp:424-443): no early return there
-      s_nfe[0][team * kNodes] = lo | (m << kPosBits); s_n0[0][team * kNodes] = 0; s_n1[0][team * kNodes] = 0;
+      fr[0] = lo | (m << kPosBits); fr[kNodes] = 0; fr[2 * kNodes] = 0;
     }
     team_sync<T>();
+    SBWT_PHASE(0);
     uint32_t n_cur = 1, cur = 0;
     for (uint32_t d = 1; d < ix.interval && n_cur && !cnt[2]; ++d) {
-      const uint64_t *cfe = s_nfe[cur] + team * kNodes, *c0 = s_n0[cur] + team * kNodes, *c1 = s_n1[cur] + team * kNodes;
-      uint64_t *xfe = s_nfe[cur ^ 1] + team * kNodes, *x0 = s_n0[cur ^ 1] + team * kNodes, *x1 = s_n1[cur ^ 1] + team * kNodes;
+      const uint64_t *cfe = fr + cur * 3u * kNodes, *c0 = cfe + kNodes, *c1 = cfe + 2 * kNodes;
+      uint64_t *xfe = fr + (cur ^ 1u) * 3u * kNodes, *x0 = xfe + kNodes, *x1 = xfe + 2 * kNodes;
       // four (node, base) items per thread at a time, phase by phase: the rank queries of all four are in flight
       // together, then the sampled-row bitmaps of their children; only the rare pushes run one after the other
       constexpr int U = 4;
@@ -600,14 +631,22 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const D
           ne[j] = lf1(ix, e, it & 3u);
           act[j] = act[j] && nf[j] < ne[j];
         }
+        bool big[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) ns[j] = act[j] ? count_sampled(nf[j], ne[j]) : 0u;
+        for (int j = 0; j < U; ++j) {
+          big[j] = T == 256 && act[j] && ne[j] - nf[j] > kBigRows;
+          ns[j] = act[j] && !big[j] ? count_sampled(nf[j], ne[j]) : 0u;
+        }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
           if (!act[j]) continue;
           const uint32_t it = it0 + (uint32_t)j * T + tid, node = it >> 2, c = it & 3u;
           uint64_t p0 = c0[node], p1 = c1[node];
           if (d <= 32u) p0 |= (uint64_t)c << (64u - 2u * d); else p1 |= (uint64_t)c << (64u - 2u * (d - 32u));
+          if (big[j]) {
+            const uint32_t at = atomicAdd(&s_nbig, 1u);  // (at most rows / kBigRows such children per level)
+            if (at < kBigMax) { s_big[at][0] = nf[j]; s_big[at][1] = ne[j]; s_big[at][2] = p0; s_big[at][3] = p1; } else cnt[2] = 1u;
+          }
           const bool single = ns[j] ? emit_node(nf[j], ne[j], d, p0, p1, L, ns[j]) : false;
           if (!single && d + 1 < ix.interval) {
             const uint32_t at = atomicAdd(&cnt[1], 1u);
@@ -615,12 +654,67 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const D
           }
         }
       }
+      SBWT_PHASE(1);
+      if (T == 256) {
+        __syncthreads();
+        const uint32_t n_big = s_nbig < kBigMax ? s_nbig : kBigMax;
+        for (uint32_t b = threadIdx.x >> 6; b < n_big; b += 4) {  // a wave per big child, a lane per block
+          const uint64_t f = s_big[b][0], e = s_big[b][1], p0 = s_big[b][2], p1 = s_big[b][3];
+          const uint64_t bf = f >> 6, be = (e - 1) >> 6;
+          for (uint64_t b0 = bf; b0 <= be; b0 += 64) {
+            const uint64_t bb = b0 + lane;
+            uint64_t bits = 0, sampled = 0, sbase = 0;
+            if (bb <= be) {
+              const Block1* blk = ix.blocks1 + bb;
+              sampled = blk->sampled;
+              sbase = blk->sampled_base;
+              const uint32_t o_lo = bb == bf ? (uint32_t)(f & 63) : 0u;
+              const uint32_t o_hi = bb == be ? (uint32_t)((e - 1) & 63) + 1u : 64u;
+              bits = sampled & below(o_hi) & ~below(o_lo);
+            }
+            const uint32_t mine = (uint32_t)__popcll(bits);
+            uint32_t inc = mine;  // hits of the blocks up to and including this lane's: slots in row order
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+              const uint32_t o = (uint32_t)__shfl_up((int)inc, sft);
+              if (lane >= (uint32_t)sft) inc += o;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)inc, 63);
+            if (total == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&cnt[0], total);
+            base = (uint32_t)__shfl((int)base, 0);
+            if (base + total > kCap) { cnt[2] = 1u; continue; }
+            uint32_t at = base + inc - mine;
+            while (bits) {
+              const uint32_t o = (uint32_t)__ffsll((unsigned long long)bits) - 1u;
+              bits &= bits - 1;
+              const uint64_t sa = ix.loc_vals[sbase + (uint64_t)__popcll(sampled & below(o))];
+              sbwt_hit h;
+              uint64_t py = (uint64_t)d << 58;
+              if (push_position_keys(ix, t_chr, t_nk, t_nv, (uint64_t)d + sa, L, a.strand, &h)) {
+                if (h.pos0 > kPosMask) cnt[2] = 1u;
+                py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+              }
+              k0[at] = p0; k1[at] = p1; pay[at] = py;
+              ++at;
+            }
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_nbig = 0;
+      }
+      SBWT_PHASE(2);
       team_sync<T>();
       n_cur = cnt[1];
       team_sync<T>();
       if (tid == 0) cnt[1] = 0;
       cur ^= 1;
       team_sync<T>();
+      SBWT_PHASE(3);
+#ifdef SBWT_PHASE_CLOCKS
+      if (tid == 0) s_phase[team][11] += 1;
+#endif
     }
     if (cnt[2]) continue;  // outgrew the team: the read stays queued for k_multi
     const uint32_t H = cnt[0];
@@ -642,6 +736,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const D
     team_sync<T>();
     bool radix = false;
     const uint16_t* ord = team_sort_rows<T>(sort_lds, H, N, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+    SBWT_PHASE(4);
     // ---- accepted hits before every place, node boundaries, the cut
     uint32_t base = 0;
     for (uint32_t c = 0; c < H; c += T) {
@@ -694,19 +789,17 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 2) void k_multi_bfs(const D
       queue[q] = kQueueDone;
       atomicAdd(a.bfs_count, 1ull);
     }
+    SBWT_PHASE(5);
+#ifdef SBWT_PHASE_CLOCKS
+    if (tid == 0) { s_phase[team][10] += 1; s_phase[team][9] += m; }
+#endif
   }
+#ifdef SBWT_PHASE_CLOCKS
+  team_sync<T>();
+  if (tid < 12 && T == 256 && kNodes == 512) atomicAdd(&g_multi_phase[tid], s_phase[team][tid]);
+#endif
 }
 
-// -DSBWT_PHASE_CLOCKS: thread 0 of every team adds the clocks each phase of a read took to g_multi_phase[] (a
-// development aid; map_pass prints the totals)
-#ifdef SBWT_PHASE_CLOCKS
-__device__ unsigned long long g_multi_phase[24];  // [0..12) wave teams, [12..24) workgroup teams
-#define SBWT_PHASE(k) do { const unsigned long long c_ = clock64(); if (tid == 0) s_phase[team][k] += c_ - ph_t; ph_t = c_; } while (0)
-#define SBWT_PHASE_MEM(k) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SBWT_PHASE(k); } while (0)
-#else
-#define SBWT_PHASE(k) do { } while (0)
-#define SBWT_PHASE_MEM(k) do { } while (0)
-#endif
 
 template <int T, bool kLds>  // kLds: the filter tables are staged in LDS (a compile-time choice: LDS reads, not flat loads)
 __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
@@ -935,7 +1028,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   }
 #ifdef SBWT_PHASE_CLOCKS
   team_sync<T>();
-  if (tid < 12) atomicAdd(&g_multi_phase[(T == 256 ? 12 : 0) + tid], s_phase[team][tid]);
+  if (tid < 12 && T == 256) atomicAdd(&g_multi_phase[12 + tid], s_phase[team][tid]);
 #endif
 }
 
