@@ -517,8 +517,9 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
   // workgroup teams: children of more than kBigRows rows are scanned by a whole wave (a lane per 64-row block), not by
   // the thread that made them -- on tie-shuffled tables the copies of a repeat stay in ONE node level after level
   constexpr uint32_t kBigRows = 128, kBigMax = 16;
-  __shared__ uint64_t s_big[kBigMax][4];     // first row, end row, prepended bases
-  __shared__ uint32_t s_nbig;
+  __shared__ uint32_t s_bigi[2][kBigMax];    // the big nodes of this level and of the next: their places in the frontier
+  __shared__ uint32_t s_nbig[2];
+  __shared__ uint8_t s_pruned_all[kTeams][3 * kNodes];  // per depth (three in rotation): the node was one sampled row
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   if (*a.overflow) return;
   const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
   uint16_t* idx_of = ord0 + 2u * kCap;
   uint16_t* acc_of = ord0 + 3u * kCap;
   uint32_t* cnt = s_cnt_all[team];
+  uint8_t* const pruned = s_pruned_all[team];
   const SortLds sort_lds{k0, k1, key, pay, ord0, ord0 + kCap, s_red_all, s_scan_all};
   if (ix.interval > 64 || ix.n_chr > 0xFFFFu) return;  // key / payload fields too narrow: k_multi
   const uint64_t qn = *queue_count;
@@ -601,65 +603,82 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     const uint32_t L = a.lens[r];
     team_sync<T>();  // the previous read is done with the team's LDS
     if (tid < 4) cnt[tid] = 0;
-    if (T == 256 && tid == 0) s_nbig = 0;
-    team_sync<T>();
+    for (uint32_t k = tid; k < 3u * kNodes; k += T) pruned[k] = 0;
     if (tid == 0) {
-      const uint32_t n0 = count_sampled(lo, res.hi);
-      if (n0) emit_node(lo, res.hi, 0, 0, 0, L, n0);  // level 0 (searcher.hpp:424-443): no early return there
       fr[0] = lo | (m << kPosBits); fr[kNodes] = 0; fr[2 * kNodes] = 0;
+      if (T == 256) { s_nbig[0] = m > kBigRows ? 1u : 0u; s_nbig[1] = 0; s_bigi[0][0] = 0; }
     }
     team_sync<T>();
     SBWT_PHASE(0);
+    // Level d: the nodes of depth d are scanned for sampled rows AND expanded into the nodes of depth d + 1, by
+    // different threads at the same time -- a node's own scan is not needed to expand it, except that a node of one
+    // sampled row has no children (searcher.hpp:495): its scan marks it, and the children made meanwhile are dropped
+    // at the next level.  So a level costs the longer of the two dependent chains (rank query; bitmap -> sampled
+    // position), not their sum.
     uint32_t n_cur = 1, cur = 0;
-    for (uint32_t d = 1; d < ix.interval && n_cur && !cnt[2]; ++d) {
+    for (uint32_t d = 0; d < ix.interval && n_cur && !cnt[2]; ++d) {
       const uint64_t *cfe = fr + cur * 3u * kNodes, *c0 = cfe + kNodes, *c1 = cfe + 2 * kNodes;
       uint64_t *xfe = fr + (cur ^ 1u) * 3u * kNodes, *x0 = xfe + kNodes, *x1 = xfe + 2 * kNodes;
-      // four (node, base) items per thread at a time, phase by phase: the rank queries of all four are in flight
-      // together, then the sampled-row bitmaps of their children; only the rare pushes run one after the other
-      constexpr int U = 4;
-      for (uint32_t it0 = 0; it0 < 4u * n_cur; it0 += (uint32_t)T * U) {
-        uint64_t nf[U], ne[U];
-        uint32_t ns[U];
-        bool act[U];
+      const uint8_t* dead_of = pruned + ((d + 2u) % 3u) * kNodes;  // marks of depth d - 1
+      uint8_t* mark = pruned + (d % 3u) * kNodes;                  // marks of depth d
+      uint8_t* wipe = pruned + ((d + 1u) % 3u) * kNodes;           // ... of depth d + 1, written at the next level
+      for (uint32_t k = tid; k < kNodes; k += T) wipe[k] = 0;
+      const uint32_t n_big = T == 256 ? (s_nbig[d & 1u] < kBigMax ? s_nbig[d & 1u] : kBigMax) : 0u;
+      const uint32_t nexp = d + 1 < ix.interval ? 4u * n_cur : 0u, nitems = nexp + n_cur;
+      const bool split = T == 256 && n_big > 0;  // the last wave takes the big nodes, the others the items
+      const uint32_t W = split ? 192u : (uint32_t)T;
+      if (!split || tid < 192u) {
+        constexpr int U = 4;
+        for (uint32_t it0 = 0; it0 < nitems; it0 += W * U) {
+          uint64_t vf[U], ve[U];   // expand: the child's rows; scan: the node's rows
+          uint32_t vn[U], node[U]; // scan: sampled rows among them
+          uint32_t kind[U];        // 0: nothing, 1: expand, 2: scan
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const uint32_t it = it0 + (uint32_t)j * T + tid;
-          act[j] = it < 4u * n_cur;
-          const uint64_t fe = cfe[act[j] ? it >> 2 : 0u];
-          const uint64_t f = fe & kPosMask, e = f + (fe >> kPosBits);
-          nf[j] = lf1(ix, f, it & 3u);
-          ne[j] = lf1(ix, e, it & 3u);
-          act[j] = act[j] && nf[j] < ne[j];
-        }
-        bool big[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          big[j] = T == 256 && act[j] && ne[j] - nf[j] > kBigRows;
-          ns[j] = act[j] && !big[j] ? count_sampled(nf[j], ne[j]) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          if (!act[j]) continue;
-          const uint32_t it = it0 + (uint32_t)j * T + tid, node = it >> 2, c = it & 3u;
-          uint64_t p0 = c0[node], p1 = c1[node];
-          if (d <= 32u) p0 |= (uint64_t)c << (64u - 2u * d); else p1 |= (uint64_t)c << (64u - 2u * (d - 32u));
-          if (big[j]) {
-            const uint32_t at = atomicAdd(&s_nbig, 1u);  // (at most rows / kBigRows such children per level)
-            if (at < kBigMax) { s_big[at][0] = nf[j]; s_big[at][1] = ne[j]; s_big[at][2] = p0; s_big[at][3] = p1; } else cnt[2] = 1u;
+          for (int j = 0; j < U; ++j) {
+            const uint32_t it = it0 + (uint32_t)j * W + tid;
+            kind[j] = it < nexp ? 1u : (it < nitems ? 2u : 0u);
+            node[j] = kind[j] == 1u ? it >> 2 : (kind[j] == 2u ? it - nexp : 0u);
+            const uint64_t fe = cfe[node[j]];
+            const uint64_t f = fe & kPosMask, e = f + ((fe >> kPosBits) & 0x7FFull);
+            if (d > 0 && dead_of[(uint32_t)(fe >> 51) & 0x3FFu]) kind[j] = 0;  // its parent was one sampled row
+            vn[j] = 0;
+            if (kind[j] == 1u) {
+              vf[j] = lf1(ix, f, it & 3u);
+              ve[j] = lf1(ix, e, it & 3u);
+              if (vf[j] >= ve[j]) kind[j] = 0;
+            } else {
+              vf[j] = f;
+              ve[j] = e;
+              if (kind[j] == 2u && (T == 64 || e - f <= kBigRows)) vn[j] = count_sampled(f, e);
+            }
           }
-          const bool single = ns[j] ? emit_node(nf[j], ne[j], d, p0, p1, L, ns[j]) : false;
-          if (!single && d + 1 < ix.interval) {
-            const uint32_t at = atomicAdd(&cnt[1], 1u);
-            if (at < kNodes) { xfe[at] = nf[j] | ((ne[j] - nf[j]) << kPosBits); x0[at] = p0; x1[at] = p1; } else cnt[2] = 1u;
+#pragma unroll
+          for (int j = 0; j < U; ++j) {
+            if (kind[j] == 1u) {
+              const uint32_t c = (it0 + (uint32_t)j * W + tid) & 3u, dd = d + 1;
+              uint64_t p0 = c0[node[j]], p1 = c1[node[j]];
+              if (dd <= 32u) p0 |= (uint64_t)c << (64u - 2u * dd); else p1 |= (uint64_t)c << (64u - 2u * (dd - 32u));
+              const uint32_t at = atomicAdd(&cnt[1], 1u);
+              if (at < kNodes) {
+                xfe[at] = vf[j] | ((ve[j] - vf[j]) << kPosBits) | ((uint64_t)node[j] << 51);
+                x0[at] = p0; x1[at] = p1;
+                if (T == 256 && ve[j] - vf[j] > kBigRows) {
+                  const uint32_t bt = atomicAdd(&s_nbig[(d + 1u) & 1u], 1u);
+                  if (bt < kBigMax) s_bigi[(d + 1u) & 1u][bt] = at; else cnt[2] = 1u;
+                }
+              } else {
+                cnt[2] = 1u;
+              }
+            } else if (kind[j] == 2u && vn[j]) {
+              const bool single = emit_node(vf[j], ve[j], d, c0[node[j]], c1[node[j]], L, vn[j]);
+              if (single && d > 0) mark[node[j]] = 1;  // (level 0, searcher.hpp:424-443, has no early return)
+            }
           }
         }
-      }
-      SBWT_PHASE(1);
-      if (T == 256) {
-        __syncthreads();
-        const uint32_t n_big = s_nbig < kBigMax ? s_nbig : kBigMax;
-        for (uint32_t b = threadIdx.x >> 6; b < n_big; b += 4) {  // a wave per big child, a lane per block
-          const uint64_t f = s_big[b][0], e = s_big[b][1], p0 = s_big[b][2], p1 = s_big[b][3];
+      } else {
+        for (uint32_t b = 0; b < n_big; ++b) {  // a wave per big node, a lane per 64-row block
+          const uint32_t bn = s_bigi[d & 1u][b];
+          const uint64_t fe = cfe[bn], f = fe & kPosMask, e = f + ((fe >> kPosBits) & 0x7FFull), p0 = c0[bn], p1 = c1[bn];
           const uint64_t bf = f >> 6, be = (e - 1) >> 6;
           for (uint64_t b0 = bf; b0 <= be; b0 += 64) {
             const uint64_t bb = b0 + lane;
@@ -701,14 +720,12 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
             }
           }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_nbig = 0;
       }
-      SBWT_PHASE(2);
+      SBWT_PHASE(1);
       team_sync<T>();
-      n_cur = cnt[1];
+      n_cur = cnt[1] < kNodes ? cnt[1] : kNodes;
       team_sync<T>();
-      if (tid == 0) cnt[1] = 0;
+      if (tid == 0) { cnt[1] = 0; if (T == 256) s_nbig[d & 1u] = 0; }
       cur ^= 1;
       team_sync<T>();
       SBWT_PHASE(3);
