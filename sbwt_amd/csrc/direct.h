@@ -2,9 +2,10 @@
 //
 // k_settle (settle.h) answers a read from its hash bucket alone, which takes two things: the caller wants no SA
 // interval, and the bases behind the located prefix fit the 32 the slot carries.  This kernel drops both conditions at
-// the price of one more access: a read of hash_order + 1 .. about hash_order + 108 bases whose first hash_order
-// bases are a located row of the table compares ALL its remaining bases with the text in front of that row's position
-// and finds the row the chain ends on, both in the ONE PosLine of the position it ends on (device_layout.h) -- the
+// the price of one more access: a read of hash_order + 1 .. hash_order + 142 bases whose first hash_order bases are
+// a located row of the table compares ALL its remaining bases with the text in front of that row's position -- the
+// first 32 of them in the bucket's slot, the last 110 .. 128 in the window of the PosLine of the position it ends on
+// (device_layout.h), which overlap or meet for such a read -- and finds the row the chain ends on in that same line: the
 // same two lines the state machine reads for such a read (search_machine.h, S_CMP), but as a streaming kernel: one
 // read per lane, no state, and every line touched by exactly one load instruction.  The PosLines of a wave's 64 reads
 // come in through eight LDS-DMA loads (global_load_lds, 16 bytes per lane): in load k lane l fetches piece l % 8 of
@@ -28,8 +29,8 @@ namespace sbwt {
 
 constexpr uint32_t kDirectBuf = 256;  // pending indices a wave holds in LDS before it reserves list slots for them
 
-// a.packed: records of 4 (kLong: 8) words; a.hits_only as SBWT_MAP_HITS_ONLY
-template <bool kLong, bool kLds>  // kLds: the filter tables are staged in LDS (as in k_settle)
+// a.packed: records of 4 * kPieces words (64, 128 or 192 bases); a.hits_only as SBWT_MAP_HITS_ONLY
+template <int kPiecesT, bool kLds>  // kLds: the filter tables are staged in LDS (as in k_settle)
 __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const SettleArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   __shared__ __attribute__((aligned(16))) uint4 s_img_all[4][512];  // per wave: the PosLines of its 64 reads (8 KB)
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
   const uint64_t hmask = (1ull << (2 * H)) - 1ull;
   const uint32_t tmask = (1u << ix.hash_tag_bits) - 1u;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  constexpr uint32_t kPieces = kLong ? 2u : 1u;  // 16-byte pieces of a record
+  constexpr uint32_t kPieces = (uint32_t)kPiecesT;  // 16-byte pieces of a record
+  constexpr bool kLong = kPiecesT >= 2, kLong3 = kPiecesT >= 3;
   constexpr uint32_t kMaxLen = 64u * kPieces;
   const uint4* const recs = reinterpret_cast<const uint4*>(a.packed);
   const uint4* const tab = reinterpret_cast<const uint4*>(ix.hash_tab);
@@ -73,26 +75,29 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
   const uint64_t n_round = (a.n_reads + 63) & ~63ull;  // whole waves stay in the loop together (ballots, DPP, LDS-DMA)
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = r < a.n_reads;
-  uint4 rec = make_uint4(0, 0, 0, 0), rec2 = rec;
+  uint4 rec = make_uint4(0, 0, 0, 0), rec2 = rec, rec3 = rec;
   uint32_t L = 0;
   if (valid) {
     rec = recs[r * kPieces];
     if (kLong) rec2 = recs[r * kPieces + 1];
+    if (kLong3) rec3 = recs[r * kPieces + 2];
     L = a.lens[r];
   }
   for (; r < n_round; r += stride) {
     // the record of the read after this one is on its way while this one's lines are awaited
     const uint64_t rn = r + stride;
     const bool nvalid = rn < a.n_reads;
-    uint4 nrec = make_uint4(0, 0, 0, 0), nrec2 = nrec;
+    uint4 nrec = make_uint4(0, 0, 0, 0), nrec2 = nrec, nrec3 = nrec;
     uint32_t nL = 0;
     if (nvalid) {
       nrec = recs[rn * kPieces];
       if (kLong) nrec2 = recs[rn * kPieces + 1];
+      if (kLong3) nrec3 = recs[rn * kPieces + 2];
       nL = a.lens[rn];
     }
 
     const uint64_t w0 = u64_of(rec.x, rec.y), w1 = u64_of(rec.z, rec.w), w2 = u64_of(rec2.x, rec2.y), w3 = u64_of(rec2.z, rec2.w);
+    const uint64_t w4 = u64_of(rec3.x, rec3.y), w5 = u64_of(rec3.z, rec3.w);
     bool pending = valid;
     uint64_t e0 = 0, e1 = 0;  // the record
     if (valid && (L < (uint32_t)kKmer || L > kMaxLen)) {
@@ -100,8 +105,9 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
       pending = false;
     }
     const uint32_t rem = L - H;
-    // (slot + rem <= 128 with slot <= 18: the rest of the read lies inside the window of its last position's PosLine)
-    const bool look = pending && L > H && rem <= 128u - (kPosPerLine - 1u);
+    // (the slot's text covers the first 32 bases behind the prefix, the window of the last position's PosLine the last
+    // 128 - slot, slot <= 18: whether they meet is known once the position is)
+    const bool look = pending && L > H && rem <= 32u + 128u;
     const uint64_t vv = hash_mix((~w0) & hmask, H);
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
@@ -123,7 +129,10 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
           uint64_t r0, r1;
           sm_funnel128(w0, w1, w2, w3, H, r0, r1);
           const uint64_t diff = (r0 ^ text) & (rem < 32u ? (1ull << (2 * rem)) - 1ull : ~0ull);
-          if (diff == 0) {
+          const uint32_t s19 = (uint32_t)((pos - rem) % kPosPerLine);
+          if (rem > 32u + 128u - s19) {
+            // the slot's text and the window leave a gap: the general kernels
+          } else if (diff == 0) {
             need_line = true;
             pfin = pos - rem;
           } else if (a.hits_only) {
@@ -160,8 +169,10 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
       const uint32_t* iw = reinterpret_cast<const uint32_t*>(im);
       const uint64_t rw = u64_of(iw[ob >> 2], iw[(ob >> 2) + 1]);
       const uint64_t row = (rw >> (8u * (ob & 3u))) & kPosMask;
-      // bases [H, L) of the read against the 128-base window from offset o on (search_machine.h, S_CMP)
-      const uint32_t o = 128u - (slot19 + rem);
+      // the last nb bases of the read, [j0, L), against the 128-base window from offset o on (search_machine.h, S_CMP);
+      // bases [H, j0) -- at most 32 -- were compared with the slot's text above
+      const uint32_t nb = rem < 128u - slot19 ? rem : 128u - slot19;
+      const uint32_t o = 128u - slot19 - nb, j0 = L - nb;
       const uint64_t q0 = u64_of(ta.x, ta.y), q1 = u64_of(ta.z, ta.w), q2 = u64_of(tb.x, tb.y), q3 = u64_of(tb.z, tb.w);
       uint64_t t0, t1, t2 = 0, t3 = 0, r0, r1, r2, r3;
       if (o < 64u) {
@@ -170,16 +181,16 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
       } else {
         sm_funnel128(q2, q3, 0, 0, o - 64u, t0, t1);
       }
-      sm_funnel128(w0, w1, w2, w3, H, r0, r1);
-      sm_funnel128(w2, w3, 0, 0, H, r2, r3);
+      sm_funnel128(w0, w1, w2, w3, j0, r0, r1);  // j0 <= H + 32 < 64
+      sm_funnel128(w2, w3, w4, w5, j0, r2, r3);
       const uint64_t d[4] = {r0 ^ t0, r1 ^ t1, r2 ^ t2, r3 ^ t3};
       bool differs = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t first = 32u * (uint32_t)q;  // this word covers bases [first, first + 32) of the rem
+        const uint32_t first = 32u * (uint32_t)q;  // this word covers bases [first, first + 32) of the nb
         uint64_t dq = d[q];
-        if (rem <= first) dq = 0;
-        else if (rem < first + 32u) dq &= (1ull << (2 * (rem - first))) - 1ull;
+        if (nb <= first) dq = 0;
+        else if (nb < first + 32u) dq &= (1ull << (2 * (nb - first))) - 1ull;
         differs = differs || dq != 0;
       }
       if (!differs) {
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     valid = nvalid;
     rec = nrec;
     rec2 = nrec2;
+    rec3 = nrec3;
     L = nL;
   }
   if (n_buf) flush_pending();

@@ -272,7 +272,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     if (e == hipSuccess) c->grid_settle = (uint32_t)(prop.multiProcessorCount * (per_cu > 0 ? per_cu : 1));
     int per_cu_d = 0;
     if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<true, true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<3, true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
     if (e == hipSuccess) c->grid_direct = (uint32_t)(prop.multiProcessorCount * (per_cu_d > 0 ? per_cu_d : 1));
   }
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
@@ -588,7 +588,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   // records hold 64 bases, k_direct (two accesses) for the other compact calls with records of 64 or 128 bases
   const bool fast = d.hash_text && d.hash_order && c->d_pend_list && !getenv("SBWT_NO_SETTLE");
   const bool settle = fast && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
-  const bool direct = fast && !settle && (words_per_read == 4 || words_per_read == 8) && d.pos_lines && !getenv("SBWT_NO_DIRECT");
+  const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !getenv("SBWT_NO_DIRECT");
   if (!settle && !direct) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
@@ -617,10 +617,15 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
   if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   else if (settle) k_settle<false><<<grid, 256, 0, c->stream>>>(d, sa);
-  else if (words_per_read == 4 && c->sort_lds_bytes) k_direct<false, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
-  else if (words_per_read == 4) k_direct<false, false><<<grid, 256, 0, c->stream>>>(d, sa);
-  else if (c->sort_lds_bytes) k_direct<true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
-  else k_direct<true, false><<<grid, 256, 0, c->stream>>>(d, sa);
+  else if (c->sort_lds_bytes) {
+    if (words_per_read == 4) k_direct<1, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+    else if (words_per_read == 8) k_direct<2, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+    else k_direct<3, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  } else {
+    if (words_per_read == 4) k_direct<1, false><<<grid, 256, 0, c->stream>>>(d, sa);
+    else if (words_per_read == 8) k_direct<2, false><<<grid, 256, 0, c->stream>>>(d, sa);
+    else k_direct<3, false><<<grid, 256, 0, c->stream>>>(d, sa);
+  }
   SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev_s[1], c->stream));
   SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
@@ -637,7 +642,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   if (n_pending) {
     if (c->pend_out_cap < n_pending) {  // grown with a quarter to spare, so that batches of similar make-up reuse it
       const uint64_t want = std::min<uint64_t>(c->max_reads, n_pending + (n_pending >> 2));
-      if (int e = ensure(&c->d_pend_packed, &c->pend_words, want * 8)) return e;  // (records of up to eight words)
+      if (int e = ensure(&c->d_pend_packed, &c->pend_words, want * 12)) return e;  // (records of up to twelve words)
       if (int e = ensure(&c->d_pend_lens, &c->pend_lens_cap, want)) return e;
       if (int e = ensure(&c->d_pend_out, &c->pend_out_cap, want)) return e;
     }

@@ -205,7 +205,7 @@ def test_reads_with_one_interval_share_a_located_list(world, monkeypatch):
     assert all(s[8] == 0 for s in stats)
 
 
-@pytest.mark.parametrize("lens_", [[32, 36, 50, 51, 52, 53, 60, 64], [65, 80, 100, 101, 120, 128]])
+@pytest.mark.parametrize("lens_", [[32, 36, 50, 51, 52, 53, 60, 64], [65, 80, 100, 101, 120, 128], [129, 140, 150, 161, 162, 163, 170, 192]])
 def test_two_access_fast_pass_reports_intervals(world, monkeypatch, lens_):
     """compact records WITH SA intervals, and records of up to 128 bases: k_direct answers the reads whose located
     prefix and PosLine settle them (bucket + one line each) and leaves the rest to the general kernels; every record
@@ -229,7 +229,9 @@ def test_two_access_fast_pass_reports_intervals(world, monkeypatch, lens_):
             ctx.close()
             ran_direct = not (mode == sb.MAP_HITS_ONLY and max(lens_) <= 64) and not off   # (hits only, short records: k_settle)
             if ran_direct:
-                assert t[3] > 0 and st[7] < 0.5 * len(reads)   # the fast pass ran and settled most reads
+                assert t[3] > 0                                # the fast pass ran ...
+                if max(lens_) <= 128:
+                    assert st[7] < 0.5 * len(reads)            # ... and settled most reads (beyond 162 bases it cannot)
             if off and mode == 0:
                 assert t[3] == 0
             meta = (rec["w1"] >> np.uint64(56)).astype(np.uint32)
