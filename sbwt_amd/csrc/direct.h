@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     const uint32_t rem = L - H;
     // (the slot's text covers the first 32 bases behind the prefix, the window of the last position's PosLine the last
     // 128 - slot, slot <= 18: whether they meet is known once the position is)
-    const bool look = pending && L > H && rem <= 32u + 128u;
+    const bool look = pending && L >= H && rem <= 32u + 128u;
     const uint64_t vv = hash_mix((~w0) & hmask, H);
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;

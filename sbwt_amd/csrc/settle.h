@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
       pending = false;
     }
     const uint32_t rem = L - H;
-    const bool look = pending && L > H && rem <= 32u;
+    const bool look = pending && L >= H && rem <= 32u;  // (L == H: the located row IS the result)
     const uint64_t vv = hash_mix((~w_lo) & hmask, H);
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
