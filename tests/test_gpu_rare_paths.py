@@ -133,7 +133,7 @@ def test_results_that_bypass_the_ring(sb, oracle, golden_indexes, golden_dir, mo
     rng = np.random.default_rng(8)
     reads = [r for r in fq_reads(os.path.join(golden_dir, "g2.fq")) if len(r) >= 12]
     rep = seq[1000:1300]
-    reads += [rep[a:a + 25] for a in range(0, 270, 5)]
+    reads += [rep[a:a + 25] for a in range(0, 270, 5)] * 3   # (three times: reads with one interval share a list, wide records too)
     while len(reads) < 3000:
         L = int(rng.integers(12, 90))
         p = int(rng.integers(0, len(seq) - L))
