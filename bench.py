@@ -542,6 +542,16 @@ def main():
         rate, pbytes = ix.probe_random_access(chains_per_lane=cpl, chain_len=64, workgroups_per_cu=8)
         probe["%d_chains_per_lane" % cpl] = round(rate / 1e9, 2)
     gather_peak = max(probe.values())
+    # ... and the same gather with what a mapping kernel cannot avoid: the address of every line comes from a streamed
+    # 16-byte record and a 16-byte result is written per line (no dependent chains, no other work)
+    stream_gather = None
+    try:
+        free_b2, _ = torch.cuda.mem_get_info()
+        n_probe = int(min(n_reads, 100_000_000, max(0, free_b2 - (2 << 30)) // 32))
+        if n_probe >= 1_000_000:
+            stream_gather = ix.probe_gather_stream(n_probe, 8) / 1e9
+    except Exception as e:  # (measurement only: an allocation failure here must not cost the bench line)
+        sys.stderr.write("stream gather probe skipped: %s\n" % e)
     lines_per_s = accesses / (dom_ms * 1e-3) / 1e9
     stored = None
     tpath = os.path.join(ROOT, "profiles", "r2", "traffic_%s.json" % args.layout)   # PMC passes of an earlier run: context only
@@ -565,6 +575,11 @@ def main():
                 "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
                                     "table_GB": round(pbytes / 1e9, 1), "by_chains_per_lane": probe, "peak": gather_peak,
                                     "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3),
+                                    "streamed_gather_G_lines_per_s": round(stream_gather, 2) if stream_gather else None,
+                                    "streamed_gather": "independent random lines whose addresses come from a streamed 16-byte record, "
+                                                       "a 16-byte result written per line, nothing else (k_probe_stream): the "
+                                                       "ceiling of a one-line-per-read mapping kernel on this device",
+                                    "kernel_frac_of_streamed_gather": round(lines_per_s / stream_gather, 3) if stream_gather else None,
                                     # the probe issues nothing but random reads; the kernel also streams its records in and
                                     # out, and those requests share the same memory pipeline: index lines + 128-byte read
                                     # requests of the streamed input + 64-byte write requests of the output

@@ -267,6 +267,10 @@ int sbwt_ctx_last_stats_ex(const sbwt_ctx *ctx, uint64_t *stats, uint32_t n);
  * three launches), *table_bytes (may be NULL) the footprint probed.  No upstream counterpart: measurement only. */
 int sbwt_probe_random_access(const sbwt_index *ix, uint32_t chains_per_lane, uint32_t chain_len,
                              uint32_t workgroups_per_cu, double *accesses_per_s, uint64_t *table_bytes);
+/* The gather as the mapping kernels meet it: n_accesses independent random 128-byte lines of the same table whose
+ * addresses come from a streamed 16-byte input record each, a 16-byte result written per access (3.2 GB of temporary
+ * device memory per 10^8 accesses).  No upstream counterpart: measurement only (bench.py, roofline.gather_roofline). */
+int sbwt_probe_gather_stream(const sbwt_index *ix, uint64_t n_accesses, uint32_t workgroups_per_cu, double *accesses_per_s);
 /* raw hipStream_t of the ctx, for callers that want to order their own work after a batch */
 void *sbwt_ctx_stream(const sbwt_ctx *ctx);
 

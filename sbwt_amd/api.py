@@ -124,6 +124,7 @@ def lib():
     L.sbwt_ctx_last_timing_ex.argtypes = [vp, p(C.c_float * 5), u32]
     L.sbwt_ctx_last_stats_ex.argtypes = [vp, p(u64 * 10), u32]
     L.sbwt_probe_random_access.argtypes = [vp, u32, u32, u32, p(C.c_double), p(u64)]
+    L.sbwt_probe_gather_stream.argtypes = [vp, u64, u32, p(C.c_double)]
     L.sbwt_ctx_stream.argtypes = [vp]
     L.sbwt_ctx_stream.restype = vp
     L.sbwt_map_fastq.argtypes = [vp, C.c_char_p, C.c_char_p, i32, i32, i32, p(u64 * 5)]
@@ -294,6 +295,12 @@ class Index:
         _check(lib().sbwt_probe_random_access(self._h, chains_per_lane, chain_len, workgroups_per_cu, C.byref(rate),
                                               C.byref(nbytes)))
         return rate.value, nbytes.value
+
+    def probe_gather_stream(self, n_accesses, workgroups_per_cu=6):
+        """sbwt_probe_gather_stream -> independent random line accesses per second, records streamed in and out"""
+        rate = C.c_double(0.0)
+        _check(lib().sbwt_probe_gather_stream(self._h, n_accesses, workgroups_per_cu, C.byref(rate)))
+        return rate.value
 
     def chr_names(self):
         return [lib().sbwt_index_chr_name(self._h, k).decode() for k in range(self.info().n_chr)]

@@ -46,9 +46,75 @@ __global__ __launch_bounds__(256) void k_probe(const uint4* __restrict__ table, 
   if (acc == 0x9e3779b9u) atomicAdd(sink, 1ull);  // keeps the loads alive; practically never true
 }
 
+// The same gather as the mapping kernels meet it: independent (not chained) random lines whose addresses come from a
+// STREAMED 16-byte input record, with a 16-byte result written per access -- records in, one table line, records out,
+// nothing else.  What k_settle's line rate is to be held against: the random reads share the memory pipeline with the
+// two streams.
+__global__ __launch_bounds__(256) void k_probe_stream(const uint4* __restrict__ table, uint64_t n_lines, const uint4* __restrict__ in,
+                                                      uint4* __restrict__ out, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 rec = make_uint4(0, 0, 0, 0);
+  if (i < n) rec = in[i];
+  for (; i < n; i += stride) {
+    uint4 nrec = make_uint4(0, 0, 0, 0);
+    if (i + stride < n) nrec = in[i + stride];  // the next record is on its way while this one's line is awaited
+    const uint64_t h = probe_mix((((uint64_t)rec.y << 32) | rec.x) ^ i);
+    const uint4 v = table[__umul64hi(h, n_lines) * 8];
+    out[i] = make_uint4(v.x ^ rec.x, v.y ^ rec.y, v.z ^ rec.z, v.w ^ rec.w);
+    rec = nrec;
+  }
+}
+
 }  // namespace sbwt
 
 using namespace sbwt;
+
+extern "C" int sbwt_probe_gather_stream(const sbwt_index* ix, uint64_t n_accesses, uint32_t workgroups_per_cu, double* accesses_per_s) {
+  if (!ix || !accesses_per_s || n_accesses == 0) {
+    set_error("sbwt_probe_gather_stream: bad argument");
+    return SBWT_ERR_ARG;
+  }
+  SBWT_HIP(hipSetDevice(ix->device));
+  const void* table = ix->d.hash_tab ? (const void*)ix->d.hash_tab : (const void*)ix->d.sa_full;
+  const uint64_t bytes = ix->d.hash_tab ? ix->d.hash_buckets * ((ix->d.hash_text ? 16ull : 8ull) * kHashSlots) : ix->d.n * 8ull;
+  const uint64_t n_lines = bytes / 128;
+  if (n_lines < 2) {
+    set_error("sbwt_probe_gather_stream: the index is too small to probe");
+    return SBWT_ERR_ARG;
+  }
+  hipDeviceProp_t prop;
+  SBWT_HIP(hipGetDeviceProperties(&prop, ix->device));
+  if (workgroups_per_cu == 0) workgroups_per_cu = 6;
+  const uint32_t grid = (uint32_t)prop.multiProcessorCount * workgroups_per_cu;
+  DevTemp<uint4> in, out;
+  SBWT_HIP(in.alloc(n_accesses));
+  SBWT_HIP(out.alloc(n_accesses));
+  SBWT_HIP(hipMemset(in, 0x5A, n_accesses * sizeof(uint4)));
+  hipEvent_t a = nullptr, b = nullptr;
+  SBWT_HIP(hipEventCreate(&a));
+  hipError_t e = hipEventCreate(&b);
+  float best = 0.f;
+  if (e == hipSuccess) {
+    k_probe_stream<<<grid, 256>>>(static_cast<const uint4*>(table), n_lines, in, out, n_accesses < 4096 ? n_accesses : 4096);  // warm-up
+    e = hipDeviceSynchronize();
+  }
+  for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {
+    e = hipEventRecord(a, nullptr);
+    k_probe_stream<<<grid, 256>>>(static_cast<const uint4*>(table), n_lines, in, out, n_accesses);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(b, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (e == hipSuccess && (best == 0.f || ms < best)) best = ms;
+  }
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  if (e != hipSuccess) return hip_fail(e, "sbwt_probe_gather_stream", __FILE__, __LINE__);
+  *accesses_per_s = best > 0.f ? (double)n_accesses / (best * 1e-3) : 0.0;
+  return SBWT_OK;
+}
 
 extern "C" int sbwt_probe_random_access(const sbwt_index* ix, uint32_t chains_per_lane, uint32_t chain_len,
                                         uint32_t workgroups_per_cu, double* accesses_per_s, uint64_t* table_bytes) {

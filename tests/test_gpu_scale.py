@@ -249,3 +249,14 @@ def test_two_access_fast_pass_reports_intervals(world, monkeypatch, lens_):
             outs.append((res, no_sa))
         np.testing.assert_array_equal(outs[0][0]["flags"], outs[1][0]["flags"])
     monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
+
+
+def test_roofline_probes_run(world):
+    """sbwt_probe_random_access / sbwt_probe_gather_stream: measurement entry points; here only that they run on a small
+    index and report a rate"""
+    sb, ix, oix, codes, fam, rng = world
+    rate, nbytes = ix.probe_random_access(chains_per_lane=2, chain_len=8, workgroups_per_cu=2)
+    assert rate > 0 and nbytes >= 128
+    assert ix.probe_gather_stream(200_000, 2) > 0
+    with pytest.raises(sb.SbwtError):
+        ix.probe_gather_stream(0)
