@@ -9,6 +9,7 @@
 // on the loaded bytes.  No upstream counterpart: measurement only (bench.py reports it beside the kernel's rate).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sbwt_amd.h"
 #include "index_impl.hpp"
@@ -50,20 +51,26 @@ __global__ __launch_bounds__(256) void k_probe(const uint4* __restrict__ table, 
 // STREAMED 16-byte input record, with a 16-byte result written per access -- records in, one table line, records out,
 // nothing else.  What k_settle's line rate is to be held against: the random reads share the memory pipeline with the
 // two streams.
+template <int kVariant>  // 0: as described; 1: no result written; 2: no record read; 3: neither; 4: 8-byte results (experiments)
 __global__ __launch_bounds__(256) void k_probe_stream(const uint4* __restrict__ table, uint64_t n_lines, const uint4* __restrict__ in,
                                                       uint4* __restrict__ out, uint64_t n) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint4 rec = make_uint4(0, 0, 0, 0);
-  if (i < n) rec = in[i];
+  constexpr bool kRead = kVariant == 0 || kVariant == 1 || kVariant == 4, kWrite = kVariant == 0 || kVariant == 2 || kVariant == 4;
+  if (kRead && i < n) rec = in[i];
+  uint32_t acc = 0;
   for (; i < n; i += stride) {
     uint4 nrec = make_uint4(0, 0, 0, 0);
-    if (i + stride < n) nrec = in[i + stride];  // the next record is on its way while this one's line is awaited
+    if (kRead && i + stride < n) nrec = in[i + stride];  // the next record is on its way while this one's line is awaited
     const uint64_t h = probe_mix((((uint64_t)rec.y << 32) | rec.x) ^ i);
     const uint4 v = table[__umul64hi(h, n_lines) * 8];
-    out[i] = make_uint4(v.x ^ rec.x, v.y ^ rec.y, v.z ^ rec.z, v.w ^ rec.w);
+    if (kVariant == 4) reinterpret_cast<uint2*>(out)[i] = make_uint2(v.x ^ rec.x, v.y ^ rec.y);
+    else if (kWrite) out[i] = make_uint4(v.x ^ rec.x, v.y ^ rec.y, v.z ^ rec.z, v.w ^ rec.w);
+    else acc += v.x ^ v.y ^ v.z ^ v.w;
     rec = nrec;
   }
+  if (!kWrite && acc == 0x9e3779b9u) out[0] = make_uint4(acc, 0, 0, 0);
 }
 
 }  // namespace sbwt
@@ -96,12 +103,21 @@ extern "C" int sbwt_probe_gather_stream(const sbwt_index* ix, uint64_t n_accesse
   hipError_t e = hipEventCreate(&b);
   float best = 0.f;
   if (e == hipSuccess) {
-    k_probe_stream<<<grid, 256>>>(static_cast<const uint4*>(table), n_lines, in, out, n_accesses < 4096 ? n_accesses : 4096);  // warm-up
+    k_probe_stream<0><<<grid, 256>>>(static_cast<const uint4*>(table), n_lines, in, out, n_accesses < 4096 ? n_accesses : 4096);  // warm-up
     e = hipDeviceSynchronize();
   }
   for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {
     e = hipEventRecord(a, nullptr);
-    k_probe_stream<<<grid, 256>>>(static_cast<const uint4*>(table), n_lines, in, out, n_accesses);
+    {
+      const char* ve = getenv("SBWT_PROBE_VARIANT");
+      const int variant = ve ? atoi(ve) : 0;
+      const uint4* t = static_cast<const uint4*>(table);
+      if (variant == 1) k_probe_stream<1><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
+      else if (variant == 2) k_probe_stream<2><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
+      else if (variant == 3) k_probe_stream<3><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
+      else if (variant == 4) k_probe_stream<4><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
+      else k_probe_stream<0><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
+    }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b, nullptr);
     if (e == hipSuccess) e = hipEventSynchronize(b);
