@@ -51,21 +51,34 @@ __global__ __launch_bounds__(256) void k_probe(const uint4* __restrict__ table, 
 // STREAMED 16-byte input record, with a 16-byte result written per access -- records in, one table line, records out,
 // nothing else.  What k_settle's line rate is to be held against: the random reads share the memory pipeline with the
 // two streams.
-template <int kVariant>  // 0: as described; 1: no result written; 2: no record read; 3: neither; 4: 8-byte results (experiments)
+template <int kVariant>  // 0: as described; 1: no result written; 2: no record read; 3: neither; 4: 8-byte results; 5: non-temporal record loads and result stores (experiments)
 __global__ __launch_bounds__(256) void k_probe_stream(const uint4* __restrict__ table, uint64_t n_lines, const uint4* __restrict__ in,
                                                       uint4* __restrict__ out, uint64_t n) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint4 rec = make_uint4(0, 0, 0, 0);
-  constexpr bool kRead = kVariant == 0 || kVariant == 1 || kVariant == 4, kWrite = kVariant == 0 || kVariant == 2 || kVariant == 4;
-  if (kRead && i < n) rec = in[i];
+  constexpr bool kRead = kVariant == 0 || kVariant == 1 || kVariant >= 4, kWrite = kVariant == 0 || kVariant == 2 || kVariant >= 4;
+  auto load_rec = [&](uint64_t k) -> uint4 {
+    if (kVariant == 5) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(in + k);
+      return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2),
+                        __builtin_nontemporal_load(q + 3));
+    }
+    return in[k];
+  };
+  if (kRead && i < n) rec = load_rec(i);
   uint32_t acc = 0;
   for (; i < n; i += stride) {
     uint4 nrec = make_uint4(0, 0, 0, 0);
-    if (kRead && i + stride < n) nrec = in[i + stride];  // the next record is on its way while this one's line is awaited
+    if (kRead && i + stride < n) nrec = load_rec(i + stride);  // the next record is on its way while this one's line is awaited
     const uint64_t h = probe_mix((((uint64_t)rec.y << 32) | rec.x) ^ i);
     const uint4 v = table[__umul64hi(h, n_lines) * 8];
     if (kVariant == 4) reinterpret_cast<uint2*>(out)[i] = make_uint2(v.x ^ rec.x, v.y ^ rec.y);
+    else if (kVariant == 5) {
+      uint32_t* q = reinterpret_cast<uint32_t*>(out + i);
+      __builtin_nontemporal_store(v.x ^ rec.x, q); __builtin_nontemporal_store(v.y ^ rec.y, q + 1);
+      __builtin_nontemporal_store(v.z ^ rec.z, q + 2); __builtin_nontemporal_store(v.w ^ rec.w, q + 3);
+    }
     else if (kWrite) out[i] = make_uint4(v.x ^ rec.x, v.y ^ rec.y, v.z ^ rec.z, v.w ^ rec.w);
     else acc += v.x ^ v.y ^ v.z ^ v.w;
     rec = nrec;
@@ -116,6 +129,7 @@ extern "C" int sbwt_probe_gather_stream(const sbwt_index* ix, uint64_t n_accesse
       else if (variant == 2) k_probe_stream<2><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
       else if (variant == 3) k_probe_stream<3><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
       else if (variant == 4) k_probe_stream<4><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
+      else if (variant == 5) k_probe_stream<5><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
       else k_probe_stream<0><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
     }
     if (e == hipSuccess) e = hipGetLastError();
