@@ -204,11 +204,6 @@ __device__ __forceinline__ uint64_t rev_bases(uint64_t x) {
   return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
 }
 
-__device__ __forceinline__ bool key_less(uint64_t a0, uint64_t a1, uint32_t a2, uint64_t b0, uint64_t b1, uint32_t b2) {
-  if (a0 != b0) return a0 < b0;
-  if (a1 != b1) return a1 < b1;
-  return a2 < b2;
-}
 
 // A team of T threads (one wave, or the whole workgroup) handles one read at a time; reads with up to
 // kSortMax / (256 / T) rows.  Launched twice: waves take the reads with at most 256 rows (four at a time per
@@ -227,51 +222,6 @@ __device__ __forceinline__ void team_sync() {
 __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, uint32_t lane_mask) {
   const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, (int)lane_mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)lane_mask);
   return ((uint64_t)hi << 32) | lo;
-}
-
-// Bitonic sort of N = T * E words held E per thread (element tid * E + k in v[k]): strides below E stay inside the
-// thread, strides below 64 * E go through lane shuffles, only the widest ones (workgroup teams) through LDS.
-template <int T, int E, typename Less>
-__device__ __forceinline__ void team_bitonic(uint64_t (&v)[4], uint32_t tid, uint64_t* xch, Less less) {
-  constexpr uint32_t N = (uint32_t)T * E;
-  for (uint32_t size = 2; size <= N; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      if (stride < (uint32_t)E) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-          if ((uint32_t)k & stride) continue;
-          const int k2 = k + (int)stride;
-          if (k2 >= E) continue;
-          const bool up = ((tid * E + (uint32_t)k) & size) == 0;
-          const uint64_t x = v[k], y = v[k2];
-          if (less(y, x) == up) { v[k] = y; v[k2] = x; }
-        }
-      } else {
-        const uint32_t tmask = stride / (uint32_t)E;  // partner thread = tid ^ tmask
-        const bool lower = (tid & tmask) == 0;
-        uint64_t other[4];
-        if (tmask < 64u) {
-#pragma unroll
-          for (int k = 0; k < E; ++k) other[k] = shfl_xor64(v[k], tmask);
-        } else {
-          __syncthreads();
-#pragma unroll
-          for (int k = 0; k < E; ++k) xch[tid * E + (uint32_t)k] = v[k];
-          __syncthreads();
-#pragma unroll
-          for (int k = 0; k < E; ++k) other[k] = xch[(tid ^ tmask) * E + (uint32_t)k];
-        }
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-          const bool up = ((tid * E + (uint32_t)k) & size) == 0;
-          // the lower element of the pair keeps the smaller word when the pair sorts upwards
-          const bool take_small = lower == up;
-          const bool other_small = less(other[k], v[k]);
-          if (other_small == take_small) v[k] = other[k];
-        }
-      }
-    }
-  }
 }
 
 // hit of one row as it waits in LDS for its place in the emission order:
