@@ -722,7 +722,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": config1,
         "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "list_hits": int(n_hits), "wide_records": n_wide_rec,
                    "reads_without_sa_interval": n_no_sa, "reads_to_multi_hit_locate": int(stats[1]),
-                   "reads_sharing_a_located_list": int(stats[8]) if len(stats) > 8 else 0, "reads_to_depth_first_locate": int(stats[3]), "of_which_level_by_level": int(stats[9]) if len(stats) > 9 else 0,
+                   "reads_sharing_a_located_list": int(stats[8]) if len(stats) > 8 else 0, "reads_to_depth_first_locate": int(stats[3]), "of_which_level_by_level": int(stats[9]) if len(stats) > 9 else 0, "reads_settled_by_a_miss": int(stats[10]) if len(stats) > 10 else 0,
                    "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
                    "fast_pass_ms": round(float(np.mean([k[3] for k in kernel_ms])), 3),
                    "pending_pass_ms": round(float(np.mean([k[4] for k in kernel_ms])), 3),

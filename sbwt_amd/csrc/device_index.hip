@@ -542,12 +542,38 @@ __global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, 
 }
 
 // ---- hash_tab: located prefixes of order K (device_layout.h) ----------------------------------------------
-// One thread per row: the K-mer in front of the row's text position, the upstream steps for that K-mer (exactly as
-// k_kmer_table runs them), and an entry only when they end on this very row, alone.
+// the slot of the mixed value vv goes into the first free slot of its bucket, then (with text, whole lines of two
+// buckets) of the other bucket of the same 128-byte line: the values of two neighbouring buckets differ by less than
+// 2^tag_bits, so the tag still tells them all apart, and k_settle looks there only when the first bucket has no free
+// slot.  Slots are never emptied again: a slot free at the end was free to every prefix that came by.
+__device__ __forceinline__ bool hash_insert(uint64_t* tab, uint64_t n_buckets, uint32_t with_text, uint64_t vv, uint32_t K, uint64_t slot,
+                                            uint64_t text) {
+  const uint64_t b = __umul64hi(vv << (64 - 2 * K), n_buckets);
+  const uint32_t stride = with_text ? 2u : 1u;  // words per slot
+  const uint32_t tries = (with_text && (n_buckets & 1ull) == 0) ? 2u * kHashSlots : kHashSlots;
+  for (uint32_t s = 0; s < tries; ++s) {
+    unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + ((s < kHashSlots ? b : (b ^ 1ull)) * kHashSlots + (s & (kHashSlots - 1))) * stride;
+    if (atomicCAS(&bk[0], ~0ull, (unsigned long long)slot) == ~0ull) {
+      if (with_text) bk[1] = text;
+      return true;
+    }
+  }
+  return false;  // both buckets full: this K-mer stays with the fallback path
+}
+
+constexpr uint32_t kHashUncoveredMax = 1u << 16;
+
+// One thread per row: the K-mer in front of the row's text position and the upstream steps for that K-mer (exactly as
+// k_kmer_table runs them).  When they end on this very row, alone: an entry with the position.  With text, when they
+// end on an interval that holds this row among others, its first row stores a MARKER (run = 0: the prefix occurs,
+// k_settle leaves the read to the general kernels), and a row the steps for ITS K-mer do not end on -- no K bases
+// behind it, not located, an order of suffixes the text does not explain -- goes to `uncovered` for k_hash_cover.
 __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets,
-                                                    uint32_t tag_bits, uint32_t with_text, unsigned long long* __restrict__ counts) {
+                                                    uint32_t tag_bits, uint32_t with_text, unsigned long long* __restrict__ counts,
+                                                    uint64_t* __restrict__ uncovered) {
   const uint64_t i = global_thread();
-  uint32_t outcome = 0;  // 1 stored, 2 left out
+  uint32_t outcome = 0;  // 1 stored, 2 left out, 3 marker stored, 4 marker left out
+  bool covered = false;
   const uint64_t e = i < ix.n ? ix.sa_full[i] : kNoPosition;
   const uint64_t p = e & kPosMask, run = e >> kPosBits;
   const uint64_t m = ix.n - 1;
@@ -572,40 +598,98 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
       hi = h1;
       alive = lo < hi;
     }
-    if (alive && hi - lo == 1 && lo == i) {
-      const uint64_t vv = hash_mix(v, K);
-      const uint64_t b = __umul64hi(vv << (64 - 2 * K), n_buckets);
+    covered = alive && lo <= i && i < hi;
+    const uint64_t vv = hash_mix(v, K);
+    const uint64_t tag = vv & ((1ull << tag_bits) - 1ull);
+    if (covered && hi - lo == 1) {
       const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
-      const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | (vv & ((1ull << tag_bits) - 1ull));
-      const uint32_t stride = with_text ? 2u : 1u;  // words per slot
-      outcome = 2;  // bucket full: this K-mer stays with the fallback path
-      // With text, a prefix that finds its bucket full goes to the other bucket of the same 128-byte line (b ^ 1): the
-      // values of two neighbouring buckets differ by less than 2^tag_bits, so the tag still tells them all apart,
-      // and k_settle looks there only when the first bucket has no free slot.
-      const uint32_t tries = (with_text && (n_buckets & 1ull) == 0) ? 2u * kHashSlots : kHashSlots;
-      for (uint32_t s = 0; s < tries; ++s) {
-        unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + ((s < kHashSlots ? b : (b ^ 1ull)) * kHashSlots + (s & (kHashSlots - 1))) * stride;
-        if (atomicCAS(&bk[0], ~0ull, (unsigned long long)slot) == ~0ull) {
-          outcome = 1;
-          if (with_text) {
-            // what the read's bases K .. K+31 are compared with: textrc[m - p ..) (search_machine.h, S_CMP: x0 = n - 1 - p)
-            const uint64_t x1 = m - p;
-            const uint32_t* ty = ix.textrc + (x1 >> 4);
-            const uint32_t sh1 = 2u * (uint32_t)(x1 & 15);
-            const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
-            bk[1] = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
-          }
-          break;
-        }
+      const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | tag;
+      uint64_t text = 0;
+      if (with_text) {
+        // what the read's bases K .. K+31 are compared with: textrc[m - p ..) (search_machine.h, S_CMP: x0 = n - 1 - p)
+        const uint64_t x1 = m - p;
+        const uint32_t* ty = ix.textrc + (x1 >> 4);
+        const uint32_t sh1 = 2u * (uint32_t)(x1 & 15);
+        const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
+        text = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
       }
+      outcome = hash_insert(tab, n_buckets, with_text, vv, K, slot, text) ? 1 : 2;
+    } else if (covered && with_text && i == lo) {
+      outcome = hash_insert(tab, n_buckets, with_text, vv, K, tag, 0) ? 3 : 4;  // position 0, run 0
     }
   }
-  // statistics: one pair of atomics per wave
-  const uint64_t stored = __ballot(outcome == 1), left = __ballot(outcome == 2);
-  if ((threadIdx.x & 63) == 0) {
-    if (stored) atomicAdd(&counts[0], (unsigned long long)__popcll(stored));
-    if (left) atomicAdd(&counts[1], (unsigned long long)__popcll(left));
+  if (with_text && i < ix.n && !covered) {
+    const unsigned long long k = atomicAdd(&counts[4], 1ull);  // (a handful of rows: the ends of the text)
+    if (k < kHashUncoveredMax) uncovered[k] = i;
   }
+  // statistics: a few atomics per wave
+  for (uint32_t o = 1; o <= 4; ++o) {
+    const uint64_t mk = __ballot(outcome == o);
+    if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&counts[o - 1], (unsigned long long)__popcll(mk));
+  }
+}
+
+// What a miss may prove rests on three facts about the tables, checked here (counts[5] += violations): c_functions
+// ascends and ends inside the rows (the intervals of different 12-mers are disjoint), and the rows LF reaches with
+// base c lie before those it reaches with base c + 1.  Together with rank being a count (lf1 never decreases in i)
+// they make the intervals of different K-mers disjoint at every order: a row lies in the interval of ONE K-mer at most.
+__global__ __launch_bounds__(256) void k_hash_checks(DeviceIndex ix, unsigned long long* __restrict__ counts) {
+  const uint64_t v = global_thread();
+  uint32_t bad = 0;
+  if (v < kNumKmer) bad += ix.c_functions[v] > ix.c_functions[v + 1];
+  if (v == 0) {
+    bad += ix.c_functions[kNumKmer] > ix.n;
+    for (uint32_t c = 0; c < 4; ++c) {
+      const uint64_t top = lf1(ix, ix.n, c), next = c < 3 ? lf1(ix, 0, c + 1) : ix.n;
+      bad += top > next || lf1(ix, 0, c) > top;
+    }
+  }
+  if (bad) atomicAdd(&counts[5], (unsigned long long)bad);
+}
+
+// One thread per uncovered row u: the ONE K-mer whose interval can hold u, found backwards.  The last step of the
+// search brought the interval into the rows of base c = digit K-1; u lies among the rows of one base only
+// (k_hash_checks), and the row j with LF_c(j) = u is unique, so the interval before that step held j: K - 12 such
+// steps back, then the 12-mer whose c_functions interval holds the row arrived at.  That K-mer gets a marker (if it
+// has no slot yet); a chain that breaks (no base reaches the row, no 12-mer holds it) means no K-mer ends on u.
+__global__ __launch_bounds__(64) void k_hash_cover(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets, uint32_t tag_bits,
+                                                   const uint64_t* __restrict__ uncovered, uint32_t n_uncovered,
+                                                   unsigned long long* __restrict__ counts) {
+  const uint64_t k = global_thread();
+  if (k >= n_uncovered) return;
+  uint64_t u = uncovered[k], v = 0;
+  for (uint32_t t = K; t-- > (uint32_t)kKmer;) {
+    uint32_t c = 4;
+    for (uint32_t q = 0; q < 4; ++q)
+      if (lf1(ix, 0, q) <= u && u < lf1(ix, ix.n, q)) c = q;
+    if (c == 4) return;
+    // smallest i in [1, n] with lf1(i, c) >= u + 1; the row is i - 1
+    uint64_t a = 1, b = ix.n;
+    while (a < b) {
+      const uint64_t mid = a + (b - a) / 2;
+      if (lf1(ix, mid, c) >= u + 1) b = mid; else a = mid + 1;
+    }
+    u = a - 1;
+    v |= (uint64_t)c << (2 * t);
+  }
+  // the 12-mer: last entry of c_functions that is <= u
+  uint64_t a = 0, b = kNumKmer;  // c_functions[0] <= u is not given: checked below
+  while (a < b) {
+    const uint64_t mid = a + (b - a + 1) / 2;
+    if (ix.c_functions[mid] <= u) a = mid; else b = mid - 1;
+  }
+  if (a >= kNumKmer || ix.c_functions[a] > u || u >= ix.c_functions[a + 1]) return;
+  v |= a;
+  const uint64_t vv = hash_mix(v, K);
+  const uint64_t tag = vv & ((1ull << tag_bits) - 1ull);
+  // already there?  (a row of an interval whose first row stored the marker; markers of the same K-mer written by
+  // two threads of this kernel are equal, which the lookups tolerate: they OR what carries the tag)
+  const uint64_t bkt = __umul64hi(vv << (64 - 2 * K), n_buckets);
+  for (uint32_t s = 0; s < 2u * kHashSlots; ++s) {
+    const uint64_t w = tab[((s < kHashSlots ? bkt : (bkt ^ 1ull)) * kHashSlots + (s & (kHashSlots - 1))) * 2u];
+    if ((w >> 32) != 0xFFFFFFFFull && ((w ^ tag) & ((1ull << tag_bits) - 1ull)) == 0) return;
+  }
+  atomicAdd(&counts[hash_insert(tab, n_buckets, 1u, vv, K, tag, 0) ? 2 : 3], 1ull);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -809,6 +893,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     d.hash_tag_bits = 0;
     d.hash_text = 0;
     d.hash_buddy = 0;
+    d.hash_complete = 0;
     // both prefix tables are optional: an allocation that fails (fragmented or shared device memory) leaves the
     // index without that table, slower and with the same results
     uint64_t* htab = nullptr;
@@ -817,22 +902,41 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       H = 0;
     }
     if (H) {
-      DevTemp<unsigned long long> d_counts;
-      SBWT_HIP(d_counts.alloc(2));
-      SBWT_HIP(hipMemset(d_counts, 0, 16));
+      DevTemp<unsigned long long> d_counts;  // [0] stored, [1] left out, [2] markers, [3] markers left out, [4] uncovered rows, [5] failed checks
+      DevTemp<uint64_t> d_uncovered;
+      SBWT_HIP(d_counts.alloc(8));
+      SBWT_HIP(d_uncovered.alloc(kHashUncoveredMax));
+      SBWT_HIP(hipMemset(d_counts, 0, 64));
       SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (slot_bytes * kHashSlots)));
-      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, d_counts);
+      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, d_counts, d_uncovered);
       SBWT_LAUNCHED();
-      unsigned long long h_counts[2];
-      SBWT_HIP(hipMemcpy(h_counts, d_counts, 16, hipMemcpyDeviceToHost));
+      unsigned long long h_counts[8];
+      SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
+      const bool buddy = with_text && (n_buckets & 1ull) == 0;
+      // a miss proves that a read maps nowhere (DeviceIndex::hash_complete) when every row is in the interval of a
+      // K-mer that has a slot or found its two buckets full: the rows k_hash_build could not account for get their
+      // K-mer from k_hash_cover, and the tables are what the argument there takes them to be (k_hash_checks)
+      bool complete = buddy && h_counts[4] <= kHashUncoveredMax && !getenv("SBWT_NO_HASH_COMPLETE");
+      if (complete) {
+        k_hash_checks<<<grid_for(kNumKmer, 256), 256>>>(d, d_counts);
+        SBWT_LAUNCHED();
+        if (h_counts[4]) {
+          k_hash_cover<<<grid_for(h_counts[4], 64), 64>>>(d, H, htab, n_buckets, tag_bits, d_uncovered, (uint32_t)h_counts[4], d_counts);
+          SBWT_LAUNCHED();
+        }
+        SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
+        complete = h_counts[5] == 0;
+      }
       if (getenv("SBWT_DEBUG"))
-        fprintf(stderr, "[sbwt debug] hash table: %llu prefixes stored, %llu left out (bucket full)\n", h_counts[0], h_counts[1]);
+        fprintf(stderr, "[sbwt debug] hash table: %llu prefixes stored, %llu left out (buckets full); %llu markers, %llu left out; %llu rows covered backwards, %llu failed checks: a miss %s\n",
+                h_counts[0], h_counts[1], h_counts[2], h_counts[3], h_counts[4], h_counts[5], complete ? "proves absence" : "proves nothing");
       d.hash_tab = htab;
       d.hash_order = H;
       d.hash_buckets = n_buckets;
       d.hash_tag_bits = tag_bits;
       d.hash_text = with_text ? 1u : 0u;
-      d.hash_buddy = (with_text && (n_buckets & 1ull) == 0) ? 1u : 0u;
+      d.hash_buddy = buddy ? 1u : 0u;
+      d.hash_complete = complete ? 1u : 0u;
     }
     d.kmer_order = K;
     d.kmer_tab = nullptr;

@@ -69,9 +69,11 @@ constexpr uint64_t kKmerRunMax = (1ull << 23) - 1;
 // are wanted (SBWT_MAP_HITS_ONLY): equal -> the one hit, different -> the interval dies; no further access.
 // A K-mer v (complemented read codes, as for kmer_tab) is mixed by an odd multiplier modulo 4^K (a bijection), the
 // bucket is the mixed value scaled to the bucket count (so the values of one bucket form an interval shorter than
-// 2^(tag_bits - 1)) and the tag its low tag_bits bits: bucket and tag identify v exactly.  Only K-mers whose
-// upstream search interval is ONE located row are in the table (and of those, the few that found their bucket full
-// are left out): a miss falls back to kmer_tab / c_functions, so the table never changes a result.
+// 2^(tag_bits - 1)) and the tag its low tag_bits bits: bucket and tag identify v exactly.  K-mers whose upstream
+// search interval is ONE located row are in the table with their position (of those, the few that found their
+// buckets full are left out): a miss falls back to kmer_tab / c_functions, so the table never changes a result.
+// With hash_text every OTHER K-mer whose interval is not empty has a MARKER slot (run = 0: "occurs, not settled
+// here"), which is what lets a miss prove that a read maps nowhere (hash_complete).
 constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
 constexpr uint32_t kHashSlots = 4;
 constexpr uint32_t kHashMaxOrder = 28;
@@ -105,6 +107,9 @@ struct DeviceIndex {
   const uint64_t* hash_tab; uint64_t hash_buckets; uint32_t hash_order; uint32_t hash_tag_bits;  // hash_order = 0: none
   uint32_t hash_buddy;      // 1 (with hash_text): a prefix whose bucket was full may sit in bucket ^ 1, the other half of its 128-byte line
   uint32_t hash_text;       // 1: 16-byte slots, the second word = the 32 bases textrc[n-1-pos .. n-1-pos+32) a read's next bases must equal
+  uint32_t hash_complete;   // 1: EVERY prefix of hash_order bases whose upstream search interval is not empty has a slot (a located
+                            // one, or a marker: run = 0) unless its two buckets are full -- a prefix that is in neither bucket while
+                            // one of them has a free slot occurs nowhere: the read maps nowhere (device_index.hip, k_hash_cover)
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     __builtin_amdgcn_wave_barrier();
     n_buf = 0;
   };
-  uint32_t looked = 0, found_n = 0, other_n = 0, lines_n = 0;
+  uint32_t looked = 0, found_n = 0, other_n = 0, lines_n = 0, absent_n = 0;
 
   const uint32_t sub = lane & 3u;
   const uint64_t n_round = (a.n_reads + 63) & ~63ull;  // whole waves stay in the loop together (ballots, DPP, LDS-DMA)
@@ -107,22 +107,30 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     const uint32_t rem = L - H;
     // (the slot's text covers the first 32 bases behind the prefix, the window of the last position's PosLine the last
     // 128 - slot, slot <= 18: whether they meet is known once the position is)
-    const bool look = pending && L >= H && rem <= 32u + 128u;
+    // (on a hash_complete index a longer read is looked up too when only hits are wanted: a prefix that occurs nowhere
+    // settles it)
+    const bool look = pending && L >= H && (rem <= 32u + 128u || (a.hits_only && ix.hash_complete));
     const uint64_t vv = hash_mix((~w0) & hmask, H);
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
     if (look) ++looked;
     uint64_t slot = ~0ull, text = 0;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text);
+    bool absent = false;
+    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent);
 
     bool missed = false;    // looked up and not in the table: the general kernels need not look again
     bool need_line = false; // second access: the PosLine of the position the read ends on
     uint64_t pfin = 0;
     if (look) {
-      missed = slot == ~0ull;
-      if (!missed) {
+      const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
+      missed = slot == ~0ull || run == 0;  // (run 0: a marker -- the prefix occurs, on several rows or on one not located)
+      if (slot == ~0ull && absent && ix.hash_complete && a.hits_only) {
+        // the first H bases occur nowhere in the text: the upstream search ends on an empty interval (searcher.hpp:406)
+        e1 = (uint64_t)R_NOSA << 56;
+        pending = false;
+        ++absent_n;
+      } else if (!missed) {
         ++found_n;
-        const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
         if (run > (uint64_t)rem && pos >= (uint64_t)rem) {
           // the first min(rem, 32) bases behind the prefix against the slot's text: a read that differs there needs no
           // second access (no hit; its dead interval, when wanted, is the general kernels' business)
@@ -241,7 +249,9 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     found_n += __shfl_xor(found_n, d);
     other_n += __shfl_xor(other_n, d);
     lines_n += __shfl_xor(lines_n, d);
+    absent_n += __shfl_xor(absent_n, d);
   }
+  if (lane == 0 && absent_n && a.absent_count) atomicAdd(a.absent_count, (unsigned long long)absent_n);
   if (lane == 0 && looked) {
     atomicAdd(a.index_accesses, (unsigned long long)looked + lines_n);
     atomicAdd(a.hash_stats, (unsigned long long)looked);

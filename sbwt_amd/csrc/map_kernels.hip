@@ -42,6 +42,7 @@ struct Counters {
   unsigned long long pending_other;   // ... of which not because their prefix is missing from hash_tab
   unsigned long long shared_count;    // multi-hit reads whose record points at the list of another read with the same interval (k_multi_share)
   unsigned long long bfs_count;       // reads of the depth-first queue located level by level (k_multi_bfs); the rest took k_multi
+  unsigned long long absent_count;    // reads the fast pass settled because their prefix occurs nowhere (DeviceIndex::hash_complete)
 };
 
 struct MapArgs {
@@ -164,7 +165,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 10;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 11;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -193,7 +194,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -592,7 +593,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   if (!settle && !direct) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
-      c->last_stats[6] = c->last_stats[7] = 0;
+      c->last_stats[6] = c->last_stats[7] = c->last_stats[10] = 0;
     }
     return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, multi_base,
                     multi_used, wide_used, accumulate, c->last_ms, c->last_stats);
@@ -609,6 +610,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.index_accesses = &c->d_ctr->index_accesses;
   sa.hash_stats = c->d_ctr->hash_stats;
   sa.pending_other = &c->d_ctr->pending_other;
+  sa.absent_count = &c->d_ctr->absent_count;
   sa.lds_tables = c->sort_lds_bytes ? 1u : 0u;
   sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
   sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
@@ -633,6 +635,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const uint64_t n_pending = c->h_ctr->pending_count;
   const bool all_missed = c->h_ctr->pending_other == 0;  // then the general kernels skip the hash table for this batch
   const uint64_t s_acc = c->h_ctr->index_accesses, s_look = c->h_ctr->hash_stats[0], s_found = c->h_ctr->hash_stats[1];
+  const uint64_t s_absent = c->h_ctr->absent_count;
   float ms_settle = 0.f;
   hipEventElapsedTime(&ms_settle, c->ev_s[0], c->ev_s[1]);
   int rc = SBWT_OK;
@@ -651,7 +654,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     SBWT_LAUNCHED();
     const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
@@ -662,13 +665,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9]};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }

@@ -662,9 +662,10 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
         found = hfound;
       }
       pf = (pf | PF_H1) & ~PF_RH1;
+      const uint64_t run = (found & 0xFFFFFFull) >> ix.hash_tag_bits;
+      if (run == 0) found = ~0ull;  // a marker (device_layout.h): the prefix occurs, but not as one located row
       tally_h += 0x10000u + (found != ~0ull ? 1u : 0u);
       if (found != ~0ull) {
-        const uint64_t run = (found & 0xFFFFFFull) >> ix.hash_tag_bits;
         nk = kKmerLocated | (found >> 24) | (run << kPosBits);
         pf |= PF_K1 | PF_KH;
       }

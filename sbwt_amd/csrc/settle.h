@@ -34,6 +34,7 @@ struct SettleArgs {
   unsigned long long* index_accesses;   // += buckets read
   unsigned long long* hash_stats;       // [0] lookups, [1] found
   unsigned long long* pending_other;    // pending reads that were not looked up and missed (long, short run, wide result)
+  unsigned long long* absent_count;     // += reads settled because their prefix occurs nowhere (DeviceIndex::hash_complete); may be null
   uint32_t lds_tables;                  // the launch carries (n_chr + 2 n_npos) * 8 bytes of LDS for the filter tables
   uint32_t ring_chr_max;                // chr_id a record holds (test knob, as in SmArgs)
   uint32_t hits_only;                   // k_direct: SBWT_MAP_HITS_ONLY (a read that differs from the text is settled: no hit)
@@ -44,8 +45,10 @@ struct SettleArgs {
 // other bucket of the same 128-byte line (device_index.hip): a second pass looks there for the reads whose first
 // bucket has the tag nowhere and no free slot.  Every lane of the wave calls this (DPP); `look` says who asks.
 // slot / text: the position word and the 32 bases behind the prefix; slot stays ~0 when the prefix is not there.
+// absent: the prefix is in neither bucket and the last one looked at has a free slot -- it never came by when the
+// table was built (slots are never emptied), which on a hash_complete index means it occurs nowhere.
 __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4* __restrict__ tab, uint64_t bucket, uint32_t tag,
-                                              uint32_t tmask, bool look, uint32_t sub, uint64_t& slot, uint64_t& text) {
+                                              uint32_t tmask, bool look, uint32_t sub, uint64_t& slot, uint64_t& text, bool& absent) {
   bool again = false;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
@@ -74,6 +77,7 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
       if (sub == (uint32_t)k && go) {
         if (any & 1u) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
         again = pass == 0 && any == 0u && ix.hash_buddy;
+        absent = any == 2u;
       }
     }
   }
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     __builtin_amdgcn_wave_barrier();
     n_buf = 0;
   };
-  uint32_t looked = 0, found_n = 0, other_n = 0;
+  uint32_t looked = 0, found_n = 0, other_n = 0, absent_n = 0;
 
   // ONE load instruction per line.  A lane that reads its 64-byte bucket through four 16-byte loads makes the second
   // to fourth wait in the vector cache behind the first one's miss (measured: TCP_PENDING_STALL_CYCLES over the whole
@@ -156,13 +160,19 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     const uint32_t tag = (uint32_t)vv & tmask;
     if (look) ++looked;
     uint64_t slot = ~0ull, text = 0;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text);
-    bool missed = false;  // looked up and not in the table: the general kernels need not look again
+    bool absent = false;
+    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent);
+    bool missed = false;  // looked up and not in the table as a located prefix: the general kernels need not look again
     if (look) {
-      missed = slot == ~0ull;
-      if (!missed) {
+      const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
+      missed = slot == ~0ull || run == 0;  // (run 0: a marker -- the prefix occurs, on several rows or on one not located)
+      if (slot == ~0ull && absent && ix.hash_complete) {
+        // the first H bases occur nowhere in the text: the upstream search ends on an empty interval (searcher.hpp:406)
+        e1 = (uint64_t)R_NOSA << 56;
+        pending = false;
+        ++absent_n;
+      } else if (!missed) {
         ++found_n;
-        const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
         if (run > (uint64_t)rem && pos >= (uint64_t)rem) {
           // bases H .. L-1 of the read against the text behind the prefix (search_machine.h, S_CMP: same orientation)
           uint64_t r0, r1;
@@ -210,7 +220,9 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     looked += __shfl_xor(looked, d);
     found_n += __shfl_xor(found_n, d);
     other_n += __shfl_xor(other_n, d);
+    absent_n += __shfl_xor(absent_n, d);
   }
+  if (lane == 0 && absent_n && a.absent_count) atomicAdd(a.absent_count, (unsigned long long)absent_n);
   if (lane == 0 && looked) {
     atomicAdd(a.index_accesses, (unsigned long long)looked);
     atomicAdd(a.hash_stats, (unsigned long long)looked);

@@ -158,6 +158,48 @@ def test_hits_only_fast_pass_settles_most_reads(world):
     ctx.close()
 
 
+@pytest.mark.parametrize("lens_", [[21, 30, 40, 50, 52], [70, 100, 128], [150, 181, 192]])
+def test_a_miss_in_the_complete_hash_table_settles_the_read(world, lens_):
+    """hash_tab holds EVERY 20-base prefix whose search interval is not empty (located, or as a marker), so a prefix
+    that is in neither bucket while one has a free slot occurs nowhere: the hits-only fast passes (k_settle for records
+    of 64 bases, k_direct beyond) report such a read as unmapped with one access.  Reads with a substitution in their
+    first 20 bases and random reads: same NH and hits as the oracle, and most of them counted in stats[10]"""
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 4000, lens_, mutate=0.0)
+    n_exact = len(reads)
+    for r in sample_reads(rng, codes, 4000, lens_, mutate=0.0):
+        q = int(rng.integers(0, 20))
+        b = bytearray(r)
+        b[q] = b"ACGT"[(b"ACGT".index(b[q]) + 1 + int(rng.integers(0, 3))) & 3]
+        reads.append(bytes(b))
+    for _ in range(2000):
+        reads.append(bytes(b"ACGT"[c] for c in rng.integers(0, 4, int(rng.choice(lens_)))))
+    for f in fam[:8]:                                    # multi-row prefixes: markers, not misses
+        reads.append(bytes(b"ACGT"[c] for c in f) + b"ACGTACGTACGTACGTACGTAC"[:max(0, min(lens_) - 30)])
+    packed, lens = sb.pack_reads(reads)
+    ctx = sb.Context(ix, len(reads))
+    lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+    rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=sb.MAP_HITS_ONLY)
+    st = ctx.last_stats_ex()
+    res, hits = sb.compact_expand(rec, lists, wide)
+    np.testing.assert_array_equal(res["nh"], nh)
+    k = np.maximum(nh, 0)
+    gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+    oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+    assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+    unmapped = int((nh[n_exact:n_exact + 6000] == 0).sum())
+    assert unmapped > 5900
+    assert st[10] > 0.85 * unmapped and st[10] <= int((nh == 0).sum())   # (the rest found both buckets full)
+    # the full records (SA interval of every read) are the general kernels' business: nothing is settled by a miss
+    rec2, lists2, wide2 = ctx.map_batch_compact(packed, lens)
+    assert ctx.last_stats_ex()[10] == 0
+    res2, hits2 = sb.compact_expand(rec2, lists2, wide2)
+    np.testing.assert_array_equal(res2["nh"], nh)
+    np.testing.assert_array_equal(res2["sa_lo"], lo)
+    np.testing.assert_array_equal(res2["sa_hi"], hi)
+    ctx.close()
+
+
 def test_reads_with_one_interval_share_a_located_list(world, monkeypatch):
     """small-RNA batches hold the same molecule many times: reads with the same interval and length are located once
     and the records of the others point at that list.  Same NH and lists as the oracle, which locates every read;
