@@ -542,23 +542,23 @@ __global__ __launch_bounds__(256) void k_kmer_table(DeviceIndex ix, uint32_t K, 
 }
 
 // ---- hash_tab: located prefixes of order K (device_layout.h) ----------------------------------------------
-// the slot of the mixed value vv goes into the first free slot of its bucket, then (with text, whole lines of two
-// buckets) of the other bucket of the same 128-byte line: the values of two neighbouring buckets differ by less than
-// 2^tag_bits, so the tag still tells them all apart, and k_settle looks there only when the first bucket has no free
-// slot.  Slots are never emptied again: a slot free at the end was free to every prefix that came by.
-__device__ __forceinline__ bool hash_insert(uint64_t* tab, uint64_t n_buckets, uint32_t with_text, uint64_t vv, uint32_t K, uint64_t slot,
-                                            uint64_t text) {
+// the slot of the mixed value vv goes into the first free slot of its bucket b, then (with text) of the other buckets
+// of its GROUP, b ^ 1, b ^ 2, ... b ^ (group - 1): the other half of its 128-byte line first, then the neighbouring
+// lines.  The values of the buckets of one group differ by less than 2^tag_bits, so the tag still tells them all
+// apart, and the lookups go on to the next bucket only when the one before has no free slot.  Slots are never emptied
+// again: a slot free at the end was free to every prefix that came by.
+__device__ __forceinline__ bool hash_insert(uint64_t* tab, uint64_t n_buckets, uint32_t with_text, uint32_t group, uint64_t vv, uint32_t K,
+                                            uint64_t slot, uint64_t text) {
   const uint64_t b = __umul64hi(vv << (64 - 2 * K), n_buckets);
   const uint32_t stride = with_text ? 2u : 1u;  // words per slot
-  const uint32_t tries = (with_text && (n_buckets & 1ull) == 0) ? 2u * kHashSlots : kHashSlots;
-  for (uint32_t s = 0; s < tries; ++s) {
-    unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + ((s < kHashSlots ? b : (b ^ 1ull)) * kHashSlots + (s & (kHashSlots - 1))) * stride;
+  for (uint32_t s = 0; s < group * kHashSlots; ++s) {
+    unsigned long long* bk = reinterpret_cast<unsigned long long*>(tab) + ((b ^ (uint64_t)(s / kHashSlots)) * kHashSlots + (s & (kHashSlots - 1))) * stride;
     if (atomicCAS(&bk[0], ~0ull, (unsigned long long)slot) == ~0ull) {
       if (with_text) bk[1] = text;
       return true;
     }
   }
-  return false;  // both buckets full: this K-mer stays with the fallback path
+  return false;  // every bucket of the group full: this K-mer stays with the fallback path
 }
 
 constexpr uint32_t kHashUncoveredMax = 1u << 16;
@@ -569,8 +569,8 @@ constexpr uint32_t kHashUncoveredMax = 1u << 16;
 // k_settle leaves the read to the general kernels), and a row the steps for ITS K-mer do not end on -- no K bases
 // behind it, not located, an order of suffixes the text does not explain -- goes to `uncovered` for k_hash_cover.
 __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets,
-                                                    uint32_t tag_bits, uint32_t with_text, unsigned long long* __restrict__ counts,
-                                                    uint64_t* __restrict__ uncovered) {
+                                                    uint32_t tag_bits, uint32_t with_text, uint32_t group,
+                                                    unsigned long long* __restrict__ counts, uint64_t* __restrict__ uncovered) {
   const uint64_t i = global_thread();
   uint32_t outcome = 0;  // 1 stored, 2 left out, 3 marker stored, 4 marker left out
   bool covered = false;
@@ -613,9 +613,9 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
         const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
         text = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
       }
-      outcome = hash_insert(tab, n_buckets, with_text, vv, K, slot, text) ? 1 : 2;
+      outcome = hash_insert(tab, n_buckets, with_text, group, vv, K, slot, text) ? 1 : 2;
     } else if (covered && with_text && i == lo) {
-      outcome = hash_insert(tab, n_buckets, with_text, vv, K, tag, 0) ? 3 : 4;  // position 0, run 0
+      outcome = hash_insert(tab, n_buckets, with_text, group, vv, K, tag, 0) ? 3 : 4;  // position 0, run 0
     }
   }
   if (with_text && i < ix.n && !covered) {
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_hash_checks(DeviceIndex ix, unsigned lo
 // steps back, then the 12-mer whose c_functions interval holds the row arrived at.  That K-mer gets a marker (if it
 // has no slot yet); a chain that breaks (no base reaches the row, no 12-mer holds it) means no K-mer ends on u.
 __global__ __launch_bounds__(64) void k_hash_cover(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets, uint32_t tag_bits,
-                                                   const uint64_t* __restrict__ uncovered, uint32_t n_uncovered,
+                                                   uint32_t group, const uint64_t* __restrict__ uncovered, uint32_t n_uncovered,
                                                    unsigned long long* __restrict__ counts) {
   const uint64_t k = global_thread();
   if (k >= n_uncovered) return;
@@ -685,11 +685,11 @@ __global__ __launch_bounds__(64) void k_hash_cover(DeviceIndex ix, uint32_t K, u
   // already there?  (a row of an interval whose first row stored the marker; markers of the same K-mer written by
   // two threads of this kernel are equal, which the lookups tolerate: they OR what carries the tag)
   const uint64_t bkt = __umul64hi(vv << (64 - 2 * K), n_buckets);
-  for (uint32_t s = 0; s < 2u * kHashSlots; ++s) {
-    const uint64_t w = tab[((s < kHashSlots ? bkt : (bkt ^ 1ull)) * kHashSlots + (s & (kHashSlots - 1))) * 2u];
+  for (uint32_t s = 0; s < group * kHashSlots; ++s) {
+    const uint64_t w = tab[((bkt ^ (uint64_t)(s / kHashSlots)) * kHashSlots + (s & (kHashSlots - 1))) * 2u];
     if ((w >> 32) != 0xFFFFFFFFull && ((w ^ tag) & ((1ull << tag_bits) - 1ull)) == 0) return;
   }
-  atomicAdd(&counts[hash_insert(tab, n_buckets, 1u, vv, K, tag, 0) ? 2 : 3], 1ull);
+  atomicAdd(&counts[hash_insert(tab, n_buckets, 1u, group, vv, K, tag, 0) ? 2 : 3], 1ull);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -855,7 +855,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     uint64_t slot_bytes = 8;
     if (H) {
       n_buckets = (raw.n * 8 / 5 + kHashSlots - 1) / kHashSlots;  // 1.6 slots per suffix
-      n_buckets += n_buckets & 1ull;                              // whole 128-byte lines of two buckets (hash_buddy)
+      n_buckets = (n_buckets + 7) & ~7ull;                        // whole groups of eight buckets, four 128-byte lines (hash_group)
       // a tag of at most 16 bits must tell the values of one bucket apart: 2^(tag_bits - 1) >= 4^H / n_buckets
       if (2 * H > 15 && n_buckets < (1ull << (2 * H - 15))) n_buckets = 1ull << (2 * H - 15);
       tag_bits = 1;
@@ -892,7 +892,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     d.hash_buckets = 0;
     d.hash_tag_bits = 0;
     d.hash_text = 0;
-    d.hash_buddy = 0;
+    d.hash_group = 1;
     d.hash_complete = 0;
     // both prefix tables are optional: an allocation that fails (fragmented or shared device memory) leaves the
     // index without that table, slower and with the same results
@@ -908,34 +908,45 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       SBWT_HIP(d_uncovered.alloc(kHashUncoveredMax));
       SBWT_HIP(hipMemset(d_counts, 0, 64));
       SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (slot_bytes * kHashSlots)));
-      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, d_counts, d_uncovered);
+      // with text a prefix may sit in any bucket of its group (hash_insert): as many buckets as the tag can tell apart,
+      // eight at most (2^tag_bits >= group * 4^H / n_buckets; a tag of at most 16 bits leaves 8 bits to `run`);
+      // SBWT_HASH_GROUP (1, 2, 4, 8) lowers it
+      uint32_t group = 1;
+      if (with_text) {
+        uint32_t want = 8;
+        if (const char* e = getenv("SBWT_HASH_GROUP")) want = (uint32_t)atoi(e);
+        for (uint32_t g = 2; g <= 8 && g <= want && n_buckets % g == 0; g *= 2) {
+          uint32_t t = tag_bits;
+          while ((n_buckets << t) < ((uint64_t)g << (2 * H))) ++t;
+          if (t > 16) break;
+          group = g;
+          tag_bits = t;
+        }
+      }
+      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, group, d_counts, d_uncovered);
       SBWT_LAUNCHED();
       unsigned long long h_counts[8];
       SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
-      const bool buddy = with_text && (n_buckets & 1ull) == 0;
-      // a miss proves that a read maps nowhere (DeviceIndex::hash_complete) when every row is in the interval of a
-      // K-mer that has a slot or found its two buckets full: the rows k_hash_build could not account for get their
-      // K-mer from k_hash_cover, and the tables are what the argument there takes them to be (k_hash_checks)
-      bool complete = buddy && h_counts[4] <= kHashUncoveredMax && !getenv("SBWT_NO_HASH_COMPLETE");
+      bool complete = with_text && h_counts[4] <= kHashUncoveredMax && !getenv("SBWT_NO_HASH_COMPLETE");
       if (complete) {
         k_hash_checks<<<grid_for(kNumKmer, 256), 256>>>(d, d_counts);
         SBWT_LAUNCHED();
         if (h_counts[4]) {
-          k_hash_cover<<<grid_for(h_counts[4], 64), 64>>>(d, H, htab, n_buckets, tag_bits, d_uncovered, (uint32_t)h_counts[4], d_counts);
+          k_hash_cover<<<grid_for(h_counts[4], 64), 64>>>(d, H, htab, n_buckets, tag_bits, group, d_uncovered, (uint32_t)h_counts[4], d_counts);
           SBWT_LAUNCHED();
         }
         SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
         complete = h_counts[5] == 0;
       }
       if (getenv("SBWT_DEBUG"))
-        fprintf(stderr, "[sbwt debug] hash table: %llu prefixes stored, %llu left out (buckets full); %llu markers, %llu left out; %llu rows covered backwards, %llu failed checks: a miss %s\n",
-                h_counts[0], h_counts[1], h_counts[2], h_counts[3], h_counts[4], h_counts[5], complete ? "proves absence" : "proves nothing");
+        fprintf(stderr, "[sbwt debug] hash table: groups of %u buckets, %u tag bits; %llu prefixes stored, %llu left out (buckets full); %llu markers, %llu left out; %llu rows covered backwards, %llu failed checks: a miss %s\n",
+                group, tag_bits, h_counts[0], h_counts[1], h_counts[2], h_counts[3], h_counts[4], h_counts[5], complete ? "proves absence" : "proves nothing");
       d.hash_tab = htab;
       d.hash_order = H;
       d.hash_buckets = n_buckets;
       d.hash_tag_bits = tag_bits;
       d.hash_text = with_text ? 1u : 0u;
-      d.hash_buddy = buddy ? 1u : 0u;
+      d.hash_group = group;
       d.hash_complete = complete ? 1u : 0u;
     }
     d.kmer_order = K;

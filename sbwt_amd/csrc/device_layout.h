@@ -105,7 +105,8 @@ struct DeviceIndex {
   // bases whose complemented 2-bit codes are v (low 40 bits lo, high 24 bits width; kKmerWide = not memoised; kKmerLocated form below)
   const uint64_t* kmer_tab; uint32_t kmer_order;  // kmer_order = 12: no table
   const uint64_t* hash_tab; uint64_t hash_buckets; uint32_t hash_order; uint32_t hash_tag_bits;  // hash_order = 0: none
-  uint32_t hash_buddy;      // 1 (with hash_text): a prefix whose bucket was full may sit in bucket ^ 1, the other half of its 128-byte line
+  uint32_t hash_group;      // 1, 2, 4 or 8 (above 1 with hash_text only): a prefix whose bucket b was full may sit in b ^ 1 (the other half of
+                            // its 128-byte line), b ^ 2, ... b ^ (hash_group - 1): the first of them that had a free slot
   uint32_t hash_text;       // 1: 16-byte slots, the second word = the 32 bases textrc[n-1-pos .. n-1-pos+32) a read's next bases must equal
   uint32_t hash_complete;   // 1: EVERY prefix of hash_order bases whose upstream search interval is not empty has a slot (a located
                             // one, or a marker: run = 0) unless its two buckets are full -- a prefix that is in neither bucket while

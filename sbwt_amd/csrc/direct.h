@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     if (look) ++looked;
     uint64_t slot = ~0ull, text = 0;
     bool absent = false;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent);
+    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent, lines_n);
 
     bool missed = false;    // looked up and not in the table: the general kernels need not look again
     bool need_line = false; // second access: the PosLine of the position the read ends on
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
   }
   if (lane == 0 && absent_n && a.absent_count) atomicAdd(a.absent_count, (unsigned long long)absent_n);
   if (lane == 0 && looked) {
-    atomicAdd(a.index_accesses, (unsigned long long)looked + lines_n);
+    atomicAdd(a.index_accesses, (unsigned long long)lines_n);
     atomicAdd(a.hash_stats, (unsigned long long)looked);
     atomicAdd(a.hash_stats + 1, (unsigned long long)found_n);
   }

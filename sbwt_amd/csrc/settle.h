@@ -31,7 +31,7 @@ struct SettleArgs {
   sbwt_compact_result* out;
   uint32_t* pending_list;               // read indices left to the general kernels
   unsigned long long* pending_count;
-  unsigned long long* index_accesses;   // += buckets read
+  unsigned long long* index_accesses;   // += 128-byte lines of the index read
   unsigned long long* hash_stats;       // [0] lookups, [1] found
   unsigned long long* pending_other;    // pending reads that were not looked up and missed (long, short run, wide result)
   unsigned long long* absent_count;     // += reads settled because their prefix occurs nowhere (DeviceIndex::hash_complete); may be null
@@ -41,31 +41,39 @@ struct SettleArgs {
 };
 
 // The four lanes of a quad look their buckets up together.  Round k: the quad loads the bucket of its lane k, lane
-// `sub` the slot `sub`, in ONE instruction.  A prefix that found its bucket full when the table was built sits in the
-// other bucket of the same 128-byte line (device_index.hip): a second pass looks there for the reads whose first
-// bucket has the tag nowhere and no free slot.  Every lane of the wave calls this (DPP); `look` says who asks.
+// `sub` the slot `sub`, in ONE instruction.  A prefix that found its bucket full when the table was built sits in
+// another bucket of its group (device_index.hip, hash_insert: b ^ 1 in the same 128-byte line, then b ^ 2, ...):
+// further passes look there for the reads whose buckets so far have the tag nowhere and no free slot.  Every lane of
+// the wave calls this (DPP); `look` says who asks.
 // slot / text: the position word and the 32 bases behind the prefix; slot stays ~0 when the prefix is not there.
-// absent: the prefix is in neither bucket and the last one looked at has a free slot -- it never came by when the
-// table was built (slots are never emptied), which on a hash_complete index means it occurs nowhere.
+// absent: the prefix is in none of the buckets looked at and the last of them has a free slot -- it never came by when
+// the table was built (slots are never emptied), which on a hash_complete index means it occurs nowhere.
+// lines += the 128-byte lines of the table this lane's lookup touched (two buckets a line).
 __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4* __restrict__ tab, uint64_t bucket, uint32_t tag,
-                                              uint32_t tmask, bool look, uint32_t sub, uint64_t& slot, uint64_t& text, bool& absent) {
+                                              uint32_t tmask, bool look, uint32_t sub, uint64_t& slot, uint64_t& text, bool& absent,
+                                              uint32_t& lines) {
   bool again = false;
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (uint32_t pass = 0; pass < ix.hash_group; ++pass) {
     const bool go = pass == 0 ? look : again;
     if (!__any(go)) break;
-    const uint64_t bk = pass == 0 ? bucket : (bucket ^ 1ull);
+    const uint64_t bk = bucket ^ (uint64_t)pass;
+    if (go && !(pass & 1u)) ++lines;
     uint4 piece[4];
     uint32_t want[4];
+    bool round_on[4];  // wave-uniform: the later passes serve few lanes, most of their rounds nobody
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const uint32_t b_lo = quad_bcast((uint32_t)bk, k), b_hi = quad_bcast((uint32_t)(bk >> 32), k);
       want[k] = quad_bcast(go ? 1u : 0u, k);
+      round_on[k] = __any(want[k]);
       piece[k] = make_uint4(~0u, ~0u, 0, 0);
+      if (!round_on[k]) continue;
+      const uint32_t b_lo = quad_bcast((uint32_t)bk, k), b_hi = quad_bcast((uint32_t)(bk >> 32), k);
       if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      if (!round_on[k]) continue;
       const uint32_t tag_k = quad_bcast(tag, k);
       const bool used = piece[k].y != 0xFFFFFFFFu;
       const bool hit = want[k] && used && ((piece[k].x ^ tag_k) & tmask) == 0;
@@ -76,7 +84,7 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
       v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
       if (sub == (uint32_t)k && go) {
         if (any & 1u) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
-        again = pass == 0 && any == 0u && ix.hash_buddy;
+        again = any == 0u;  // full, and the tag nowhere: on to the next bucket of the group, if there is one
         absent = any == 2u;
       }
     }
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     __builtin_amdgcn_wave_barrier();
     n_buf = 0;
   };
-  uint32_t looked = 0, found_n = 0, other_n = 0, absent_n = 0;
+  uint32_t looked = 0, found_n = 0, other_n = 0, absent_n = 0, lines_n = 0;
 
   // ONE load instruction per line.  A lane that reads its 64-byte bucket through four 16-byte loads makes the second
   // to fourth wait in the vector cache behind the first one's miss (measured: TCP_PENDING_STALL_CYCLES over the whole
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     if (look) ++looked;
     uint64_t slot = ~0ull, text = 0;
     bool absent = false;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent);
+    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent, lines_n);
     bool missed = false;  // looked up and not in the table as a located prefix: the general kernels need not look again
     if (look) {
       const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
@@ -221,10 +229,11 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     found_n += __shfl_xor(found_n, d);
     other_n += __shfl_xor(other_n, d);
     absent_n += __shfl_xor(absent_n, d);
+    lines_n += __shfl_xor(lines_n, d);
   }
   if (lane == 0 && absent_n && a.absent_count) atomicAdd(a.absent_count, (unsigned long long)absent_n);
   if (lane == 0 && looked) {
-    atomicAdd(a.index_accesses, (unsigned long long)looked);
+    atomicAdd(a.index_accesses, (unsigned long long)lines_n);
     atomicAdd(a.hash_stats, (unsigned long long)looked);
     atomicAdd(a.hash_stats + 1, (unsigned long long)found_n);
   }

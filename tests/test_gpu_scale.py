@@ -21,14 +21,35 @@ def pack_codes(codes):
     return (buf.reshape(words, 16) << sh).sum(axis=1).astype(np.uint32)
 
 
+CHR_START = np.array([0, 1_200_000, 2_100_000], dtype=np.uint64)
+NPOS_KEY = np.array([0, 400_000, 1_200_000, 2_100_000, 2_600_000, 3_000_000], dtype=np.uint64)
+NPOS_VAL = np.array([1000, 51000, 500, 0, 77, 0], dtype=np.uint64)
+
+
+def build_index(sb, codes, env, want_tables=False):
+    """index of the packed genome, built on the GPU under the given environment (prefix-table knobs)"""
+    hip = C.CDLL("libamdhip64.so.7")       # the runtime libsbwt_amd.so loaded (no torch here: a second HIP runtime in one
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]   # process that initialises after the first sees no GPU)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    host = np.concatenate([pack_codes(codes), np.zeros(4, np.uint32)])
+    d_fwd = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_fwd), host.nbytes) == 0
+    assert hip.hipMemcpy(d_fwd, host.ctypes.data, host.nbytes, 1) == 0
+    os.environ.update(env)
+    try:
+        return sb.build_index_device(d_fwd.value, len(codes), CHR_START, NPOS_KEY, NPOS_VAL, interval=64, device=0,
+                                     want_index=True, want_tables=want_tables)
+    finally:
+        for k in env:
+            os.environ.pop(k)
+        hip.hipFree(d_fwd)
+
+
 @pytest.fixture(scope="module")
 def world(oracle):
     import sbwt_amd as sb
     sb.device_count()                      # loads libsbwt_amd.so and, with it, the HIP runtime
-    hip = C.CDLL("libamdhip64.so.7")       # the same runtime (no torch here: a second HIP runtime in one process
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]   # that initialises after the first sees no GPU)
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipFree.argtypes = [C.c_void_p]
     rng = np.random.default_rng(2024)
     g = 3_000_000
     codes = rng.integers(0, 4, g).astype(np.uint8)
@@ -41,20 +62,9 @@ def world(oracle):
         for _ in range(c):
             codes[slots[k]: slots[k] + 30] = f
             k += 1
-    chr_start = np.array([0, 1_200_000, 2_100_000], dtype=np.uint64)
-    npos_key = np.array([0, 400_000, 1_200_000, 2_100_000, 2_600_000, g], dtype=np.uint64)
-    npos_val = np.array([1000, 51000, 500, 0, 77, 0], dtype=np.uint64)
-    host = np.concatenate([pack_codes(codes), np.zeros(4, np.uint32)])
-    d_fwd = C.c_void_p()
-    assert hip.hipMalloc(C.byref(d_fwd), host.nbytes) == 0
-    assert hip.hipMemcpy(d_fwd, host.ctypes.data, host.nbytes, 1) == 0
-    os.environ["SBWT_HASH_ORDER"] = "20"     # (an index of 2^22 suffixes or more gets it by itself; stated for clarity)
-    try:
-        ix, tables = sb.build_index_device(d_fwd.value, g, chr_start, npos_key, npos_val, interval=64, device=0,
-                                           want_index=True, want_tables=True)
-    finally:
-        os.environ.pop("SBWT_HASH_ORDER")
-    hip.hipFree(d_fwd)
+    chr_start, npos_key, npos_val = CHR_START, NPOS_KEY, NPOS_VAL
+    # (an index of 2^22 suffixes or more gets the order-20 hash table by itself; stated for clarity)
+    ix, tables = build_index(sb, codes, {"SBWT_HASH_ORDER": "20"}, want_tables=True)
     T = tables.contents
     L_ = oracle.lib()
     c4 = (C.c_uint64 * 4)(*T.c_function4)
@@ -198,6 +208,57 @@ def test_a_miss_in_the_complete_hash_table_settles_the_read(world, lens_):
     np.testing.assert_array_equal(res2["sa_lo"], lo)
     np.testing.assert_array_equal(res2["sa_hi"], hi)
     ctx.close()
+
+
+@pytest.mark.parametrize("env", [{"SBWT_HASH_ORDER": "16"}, {"SBWT_HASH_ORDER": "16", "SBWT_HASH_GROUP": "2"},
+                                 {"SBWT_HASH_ORDER": "17", "SBWT_HASH_GROUP": "1"}, {"SBWT_HASH_ORDER": "16", "SBWT_NO_HASH_COMPLETE": "1"}])
+def test_crowded_hash_table_groups_of_buckets(world, env):
+    """an order-16 table over this genome is as crowded as the order-20 one of a human genome (1.6 slots per suffix,
+    where the order-20 table of the other tests is nearly empty: its tag needs 2^25 buckets): prefixes overflow into
+    the other buckets of their group (eight, four 128-byte lines; SBWT_HASH_GROUP lowers it) and some misses meet full
+    buckets.  Same results as the oracle whatever the group; a miss settles reads only on a complete table"""
+    sb, ix0, oix, codes, fam, rng = world
+    ix, _ = build_index(sb, codes, env)
+    H = int(env["SBWT_HASH_ORDER"])
+    try:
+        assert ix.info().hash_order == H
+        reads = sample_reads(rng, codes, 6000, [30, 36, 48, 80, 100], mutate=0.0)
+        for r in sample_reads(rng, codes, 6000, [30, 36, 48, 80, 100], mutate=0.0):
+            q = int(rng.integers(0, H))
+            b = bytearray(r)
+            b[q] = b"ACGT"[(b"ACGT".index(b[q]) + 1 + int(rng.integers(0, 3))) & 3]
+            reads.append(bytes(b))
+        for f in fam[:12]:
+            reads.append(bytes(b"ACGT"[c] for c in f))
+        lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+        for lens_sel in (lambda L: L <= 48, lambda L: L > 0):     # records of 64 bases (k_settle), then of 128 (k_direct)
+            sel = [r for r in reads if lens_sel(len(r))]
+            idx = np.array([i for i, r in enumerate(reads) if lens_sel(len(r))])
+            packed, lens = sb.pack_reads(sel)
+            ctx = sb.Context(ix, len(sel))
+            rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=sb.MAP_HITS_ONLY)
+            st = ctx.last_stats_ex()
+            res, hits = sb.compact_expand(rec, lists, wide)
+            np.testing.assert_array_equal(res["nh"], nh[idx])
+            k = np.maximum(nh[idx], 0)
+            gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            oi = np.repeat(first[idx], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+            unmapped = int((nh[idx] == 0).sum())
+            if "SBWT_NO_HASH_COMPLETE" in env:
+                assert st[10] == 0
+            else:
+                assert 0.5 * unmapped < st[10] <= unmapped
+            assert st[5] > 0.8 * int((nh[idx] == 1).sum())        # the located prefixes are found, wherever they sit
+            # full records: the SA interval of every read
+            rec2, lists2, wide2 = ctx.map_batch_compact(packed, lens)
+            res2, hits2 = sb.compact_expand(rec2, lists2, wide2)
+            np.testing.assert_array_equal(res2["nh"], nh[idx])
+            np.testing.assert_array_equal(res2["sa_lo"], lo[idx])
+            np.testing.assert_array_equal(res2["sa_hi"], hi[idx])
+            ctx.close()
+    finally:
+        ix.close()
 
 
 def test_reads_with_one_interval_share_a_located_list(world, monkeypatch):
