@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
   };
   uint32_t looked = 0, found_n = 0, other_n = 0, lines_n = 0, absent_n = 0;
 
-  const uint32_t sub = lane & 3u;
   const uint64_t n_round = (a.n_reads + 63) & ~63ull;  // whole waves stay in the loop together (ballots, DPP, LDS-DMA)
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = r < a.n_reads;
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     if (look) ++looked;
     uint64_t slot = ~0ull, text = 0;
     bool absent = false;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent, lines_n);
+    settle_lookup(ix, tab, bucket, tag, tmask, look, lane, s_img, slot, text, absent, lines_n);  // (s_img: free until the lines arrive)
 
     bool missed = false;    // looked up and not in the table: the general kernels need not look again
     bool need_line = false; // second access: the PosLine of the position the read ends on

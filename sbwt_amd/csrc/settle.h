@@ -41,17 +41,23 @@ struct SettleArgs {
 };
 
 // The four lanes of a quad look their buckets up together.  Round k: the quad loads the bucket of its lane k, lane
-// `sub` the slot `sub`, in ONE instruction.  A prefix that found its bucket full when the table was built sits in
-// another bucket of its group (device_index.hip, hash_insert: b ^ 1 in the same 128-byte line, then b ^ 2, ...):
-// further passes look there for the reads whose buckets so far have the tag nowhere and no free slot.  Every lane of
-// the wave calls this (DPP); `look` says who asks.
+// `sub` the slot `sub`, in ONE instruction (a lane that reads its 64-byte bucket through four loads of its own makes
+// three of them wait in the vector cache behind the first one's miss) -- an LDS-DMA load: the 16 bytes go straight
+// to LDS (wave base + 16 * loading lane, masked-off lanes write nothing), where lane k then finds its whole bucket
+// and compares the four tags itself.  No exchange between lanes, which is what the kernel's VALU budget wants: a
+// fifth of k_settle's instructions used to be the DPP reduction that brought every lane its slot.
+// A prefix that found its bucket full when the table was built sits in another bucket of its group
+// (device_index.hip, hash_insert: b ^ 1 in the same 128-byte line, then b ^ 2, ...): further passes look there for the
+// reads whose buckets so far have the tag nowhere and no free slot.  Every lane of the wave calls this; `look` says
+// who asks.  s_bkt: 256 uint4 of LDS owned by this wave.
 // slot / text: the position word and the 32 bases behind the prefix; slot stays ~0 when the prefix is not there.
 // absent: the prefix is in none of the buckets looked at and the last of them has a free slot -- it never came by when
 // the table was built (slots are never emptied), which on a hash_complete index means it occurs nowhere.
 // lines += the 128-byte lines of the table this lane's lookup touched (two buckets a line).
 __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4* __restrict__ tab, uint64_t bucket, uint32_t tag,
-                                              uint32_t tmask, bool look, uint32_t sub, uint64_t& slot, uint64_t& text, bool& absent,
-                                              uint32_t& lines) {
+                                              uint32_t tmask, bool look, uint32_t lane, uint4* s_bkt, uint64_t& slot, uint64_t& text,
+                                              bool& absent, uint32_t& lines) {
+  const uint32_t sub = lane & 3u;
   bool again = false;
 #pragma unroll 1
   for (uint32_t pass = 0; pass < ix.hash_group; ++pass) {
@@ -59,35 +65,40 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
     if (!__any(go)) break;
     const uint64_t bk = bucket ^ (uint64_t)pass;
     if (go && !(pass & 1u)) ++lines;
-    uint4 piece[4];
-    uint32_t want[4];
-    bool round_on[4];  // wave-uniform: the later passes serve few lanes, most of their rounds nobody
+    const uintptr_t ba = reinterpret_cast<uintptr_t>(tab + bk * 4u);
+    const uint32_t ba_lo = (uint32_t)ba, ba_hi = (uint32_t)(ba >> 32);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      want[k] = quad_bcast(go ? 1u : 0u, k);
-      round_on[k] = __any(want[k]);
-      piece[k] = make_uint4(~0u, ~0u, 0, 0);
-      if (!round_on[k]) continue;
-      const uint32_t b_lo = quad_bcast((uint32_t)bk, k), b_hi = quad_bcast((uint32_t)(bk >> 32), k);
-      if (want[k]) piece[k] = tab[u64_of(b_lo, b_hi) * 4u + sub];
+      const uint32_t want = quad_bcast(go ? 1u : 0u, k);
+      if (!__any(want)) continue;  // wave-uniform: the later passes serve few lanes, most of their rounds nobody
+      const uintptr_t q = u64_of(quad_bcast(ba_lo, k), quad_bcast(ba_hi, k)) + 16u * sub;
+      if (want)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                         (__attribute__((address_space(3))) void*)(s_bkt + 64 * k), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (go) {
+      const uint4* im = s_bkt + 64u * sub + (lane & ~3u);  // round `sub` served this lane; its quad's four loads lie together
+      bool found = false, free_slot = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!round_on[k]) continue;
-      const uint32_t tag_k = quad_bcast(tag, k);
-      const bool used = piece[k].y != 0xFFFFFFFFu;
-      const bool hit = want[k] && used && ((piece[k].x ^ tag_k) & tmask) == 0;
-      // at most one slot of the two buckets carries the tag: OR the (masked) slot over the quad
-      uint32_t v0 = hit ? piece[k].x : 0u, v1 = hit ? piece[k].y : 0u, v2 = hit ? piece[k].z : 0u, v3 = hit ? piece[k].w : 0u;
-      uint32_t any = (hit ? 1u : 0u) | (used ? 0u : 2u);  // bit 0: found; bit 1: a free slot (nothing was ever displaced)
-      v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); v2 |= quad_swap1(v2); v3 |= quad_swap1(v3); any |= quad_swap1(any);
-      v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); v2 |= quad_swap2(v2); v3 |= quad_swap2(v3); any |= quad_swap2(any);
-      if (sub == (uint32_t)k && go) {
-        if (any & 1u) { slot = u64_of(v0, v1); text = u64_of(v2, v3); }
-        again = any == 0u;  // full, and the tag nowhere: on to the next bucket of the group, if there is one
-        absent = any == 2u;
+      for (int q = 0; q < 4; ++q) {
+        const uint4 e = im[q];
+        const bool used = e.y != 0xFFFFFFFFu;
+        free_slot = free_slot || !used;
+        if (used && ((e.x ^ tag) & tmask) == 0) {  // at most one slot of the group carries the tag
+          slot = u64_of(e.x, e.y);
+          text = u64_of(e.z, e.w);
+          found = true;
+        }
       }
+      again = !found && !free_slot;  // full, and the tag nowhere: on to the next bucket of the group, if there is one
+      absent = !found && free_slot;
     }
+    // the next pass (and the caller) may load into s_bkt again: not before these reads have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -119,7 +130,9 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
   // (same-address atomics run at about 1.2e8 per second on this device; one per wave and step would cost more than the
   // whole pass)
   __shared__ uint32_t s_pend_all[4][kSettleBuf];
+  __shared__ __attribute__((aligned(16))) uint4 s_bkt_all[4][256];  // settle_lookup: the buckets of a wave's 64 reads
   uint32_t* const s_pend = s_pend_all[threadIdx.x >> 6];
+  uint4* const s_bkt = s_bkt_all[threadIdx.x >> 6];
   uint32_t n_buf = 0;  // wave-uniform
   auto flush_pending = [&]() {
     unsigned long long base = 0;
@@ -139,7 +152,6 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
   // run of the kernel, 0.035 lines per cycle and CU against the 0.078 of the random-access probe).  So the four lanes
   // of a quad fetch one bucket together, 16 bytes each in the same instruction -- four instructions serve the four
   // reads of the quad, each line touched by exactly one -- and DPP moves inside the quad bring every read its slot.
-  const uint32_t sub = lane & 3u;  // this lane's slot within a bucket; also its turn within the quad
   const uint64_t n_round = (a.n_reads + 63) & ~63ull;  // whole waves stay in the loop together (ballots, DPP)
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = r < a.n_reads;
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     if (look) ++looked;
     uint64_t slot = ~0ull, text = 0;
     bool absent = false;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, sub, slot, text, absent, lines_n);
+    settle_lookup(ix, tab, bucket, tag, tmask, look, lane, s_bkt, slot, text, absent, lines_n);
     bool missed = false;  // looked up and not in the table as a located prefix: the general kernels need not look again
     if (look) {
       const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
