@@ -49,11 +49,13 @@ struct SettleArgs {
 // A prefix that found its bucket full when the table was built sits in another bucket of its group
 // (device_index.hip, hash_insert: b ^ 1 in the same 128-byte line, then b ^ 2, ...): further passes look there for the
 // reads whose buckets so far have the tag nowhere and no free slot.  Every lane of the wave calls this; `look` says
-// who asks.  s_bkt: 256 uint4 of LDS owned by this wave.
+// who asks.  s_bkt: kBktLds uint4 of LDS owned by this wave (a round's 64 slots, then one slot of padding: the four
+// lanes of a quad read their buckets 1040 bytes apart, in different banks).
 // slot / text: the position word and the 32 bases behind the prefix; slot stays ~0 when the prefix is not there.
 // absent: the prefix is in none of the buckets looked at and the last of them has a free slot -- it never came by when
 // the table was built (slots are never emptied), which on a hash_complete index means it occurs nowhere.
 // lines += the 128-byte lines of the table this lane's lookup touched (two buckets a line).
+constexpr uint32_t kBktRound = 65, kBktLds = 4 * kBktRound;
 __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4* __restrict__ tab, uint64_t bucket, uint32_t tag,
                                               uint32_t tmask, bool look, uint32_t lane, uint4* s_bkt, uint64_t& slot, uint64_t& text,
                                               bool& absent, uint32_t& lines) {
@@ -74,13 +76,13 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
       const uintptr_t q = u64_of(quad_bcast(ba_lo, k), quad_bcast(ba_hi, k)) + 16u * sub;
       if (want)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
-                                         (__attribute__((address_space(3))) void*)(s_bkt + 64 * k), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(s_bkt + kBktRound * k), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (go) {
-      const uint4* im = s_bkt + 64u * sub + (lane & ~3u);  // round `sub` served this lane; its quad's four loads lie together
+      const uint4* im = s_bkt + kBktRound * sub + (lane & ~3u);  // round `sub` served this lane; its quad's four loads lie together
       bool found = false, free_slot = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
   // (same-address atomics run at about 1.2e8 per second on this device; one per wave and step would cost more than the
   // whole pass)
   __shared__ uint32_t s_pend_all[4][kSettleBuf];
-  __shared__ __attribute__((aligned(16))) uint4 s_bkt_all[4][256];  // settle_lookup: the buckets of a wave's 64 reads
+  __shared__ __attribute__((aligned(16))) uint4 s_bkt_all[4][kBktLds];  // settle_lookup: the buckets of a wave's 64 reads
   uint32_t* const s_pend = s_pend_all[threadIdx.x >> 6];
   uint4* const s_bkt = s_bkt_all[threadIdx.x >> 6];
   uint32_t n_buf = 0;  // wave-uniform
