@@ -561,7 +561,6 @@ __device__ __forceinline__ bool hash_insert(uint64_t* tab, uint64_t n_buckets, u
   return false;  // every bucket of the group full: this K-mer stays with the fallback path
 }
 
-constexpr uint32_t kHashUncoveredMax = 1u << 16;
 
 // One thread per row: the K-mer in front of the row's text position and the upstream steps for that K-mer (exactly as
 // k_kmer_table runs them).  When they end on this very row, alone: an entry with the position.  With text, when they
@@ -570,14 +569,16 @@ constexpr uint32_t kHashUncoveredMax = 1u << 16;
 // behind it, not located, an order of suffixes the text does not explain -- goes to `uncovered` for k_hash_cover.
 __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets,
                                                     uint32_t tag_bits, uint32_t with_text, uint32_t group,
-                                                    unsigned long long* __restrict__ counts, uint64_t* __restrict__ uncovered) {
+                                                    unsigned long long* __restrict__ counts, uint64_t* __restrict__ uncovered,
+                                                    uint64_t uncovered_cap) {
   const uint64_t i = global_thread();
   uint32_t outcome = 0;  // 1 stored, 2 left out, 3 marker stored, 4 marker left out
   bool covered = false;
   const uint64_t e = i < ix.n ? ix.sa_full[i] : kNoPosition;
   const uint64_t p = e & kPosMask, run = e >> kPosBits;
   const uint64_t m = ix.n - 1;
-  if (e != kNoPosition && run >= 1 && p + K <= m) {  // K real bases behind the position
+  // (with text every located row is looked at: one whose run is 0 gets no entry of its own, but its K-mer a marker)
+  if (e != kNoPosition && (run >= 1 || with_text) && p + K <= m) {  // K real bases behind the position
     // digit t of v = complemented code of read[t] = 3 - textrc[x0 + t], x0 = m - p - K
     const uint64_t x0 = m - p - K;
     const uint32_t* tx = ix.textrc + (x0 >> 4);
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
     covered = alive && lo <= i && i < hi;
     const uint64_t vv = hash_mix(v, K);
     const uint64_t tag = vv & ((1ull << tag_bits) - 1ull);
-    if (covered && hi - lo == 1) {
+    if (covered && hi - lo == 1 && run >= 1) {
       const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
       const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | tag;
       uint64_t text = 0;
@@ -619,8 +620,8 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
     }
   }
   if (with_text && i < ix.n && !covered) {
-    const unsigned long long k = atomicAdd(&counts[4], 1ull);  // (a handful of rows: the ends of the text)
-    if (k < kHashUncoveredMax) uncovered[k] = i;
+    const unsigned long long k = atomicAdd(&counts[4], 1ull);  // (a handful of rows on a fully sorted index: the ends of the text)
+    if (k < uncovered_cap) uncovered[k] = i;
   }
   // statistics: a few atomics per wave
   for (uint32_t o = 1; o <= 4; ++o) {
@@ -653,15 +654,17 @@ __global__ __launch_bounds__(256) void k_hash_checks(DeviceIndex ix, unsigned lo
 // steps back, then the 12-mer whose c_functions interval holds the row arrived at.  That K-mer gets a marker (if it
 // has no slot yet); a chain that breaks (no base reaches the row, no 12-mer holds it) means no K-mer ends on u.
 __global__ __launch_bounds__(64) void k_hash_cover(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets, uint32_t tag_bits,
-                                                   uint32_t group, const uint64_t* __restrict__ uncovered, uint32_t n_uncovered,
+                                                   uint32_t group, const uint64_t* __restrict__ uncovered, uint64_t n_uncovered,
                                                    unsigned long long* __restrict__ counts) {
   const uint64_t k = global_thread();
   if (k >= n_uncovered) return;
   uint64_t u = uncovered[k], v = 0;
+  uint64_t first[4], end[4];  // the rows LF reaches with each base
+  for (uint32_t q = 0; q < 4; ++q) { first[q] = lf1(ix, 0, q); end[q] = lf1(ix, ix.n, q); }
   for (uint32_t t = K; t-- > (uint32_t)kKmer;) {
     uint32_t c = 4;
     for (uint32_t q = 0; q < 4; ++q)
-      if (lf1(ix, 0, q) <= u && u < lf1(ix, ix.n, q)) c = q;
+      if (first[q] <= u && u < end[q]) c = q;
     if (c == 4) return;
     // smallest i in [1, n] with lf1(i, c) >= u + 1; the row is i - 1
     uint64_t a = 1, b = ix.n;
@@ -905,7 +908,15 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       DevTemp<unsigned long long> d_counts;  // [0] stored, [1] left out, [2] markers, [3] markers left out, [4] uncovered rows, [5] failed checks
       DevTemp<uint64_t> d_uncovered;
       SBWT_HIP(d_counts.alloc(8));
-      SBWT_HIP(d_uncovered.alloc(kHashUncoveredMax));
+      // rows k_hash_build cannot account for: a handful on a fully sorted index, every row of an LF-inconsistent region
+      // on an index whose suffix order stops at sort_len (the reference's own builder): room for a sixteenth of the rows
+      // where the device has it, else for 65,536 (more uncovered rows than the list holds: no proof, same results)
+      uint64_t uncovered_cap = std::min<uint64_t>(raw.n / 16 + 65536, 1ull << 28);
+      if (d_uncovered.alloc(uncovered_cap) != hipSuccess) {
+        (void)hipGetLastError();
+        uncovered_cap = 65536;
+        SBWT_HIP(d_uncovered.alloc(uncovered_cap));
+      }
       SBWT_HIP(hipMemset(d_counts, 0, 64));
       SBWT_HIP(hipMemset(htab, 0xff, n_buckets * (slot_bytes * kHashSlots)));
       // with text a prefix may sit in any bucket of its group (hash_insert): as many buckets as the tag can tell apart,
@@ -923,16 +934,16 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
           tag_bits = t;
         }
       }
-      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, group, d_counts, d_uncovered);
+      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, group, d_counts, d_uncovered, uncovered_cap);
       SBWT_LAUNCHED();
       unsigned long long h_counts[8];
       SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
-      bool complete = with_text && h_counts[4] <= kHashUncoveredMax && !getenv("SBWT_NO_HASH_COMPLETE");
+      bool complete = with_text && h_counts[4] <= uncovered_cap && !getenv("SBWT_NO_HASH_COMPLETE");
       if (complete) {
         k_hash_checks<<<grid_for(kNumKmer, 256), 256>>>(d, d_counts);
         SBWT_LAUNCHED();
         if (h_counts[4]) {
-          k_hash_cover<<<grid_for(h_counts[4], 64), 64>>>(d, H, htab, n_buckets, tag_bits, group, d_uncovered, (uint32_t)h_counts[4], d_counts);
+          k_hash_cover<<<grid_for(h_counts[4], 64), 64>>>(d, H, htab, n_buckets, tag_bits, group, d_uncovered, (uint64_t)h_counts[4], d_counts);
           SBWT_LAUNCHED();
         }
         SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
