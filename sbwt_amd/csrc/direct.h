@@ -30,7 +30,7 @@ namespace sbwt {
 constexpr uint32_t kDirectBuf = 256;  // pending indices a wave holds in LDS before it reserves list slots for them
 
 // a.packed: records of 4 * kPieces words (64, 128 or 192 bases); a.hits_only as SBWT_MAP_HITS_ONLY
-template <int kPiecesT, bool kLds>  // kLds: the filter tables are staged in LDS (as in k_settle)
+template <int kPiecesT, bool kLds, bool kPlain = false>  // kLds: the filter tables are staged in LDS (as in k_settle); kPlain: 32-byte records + hits[]
 __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const SettleArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   __shared__ __attribute__((aligned(16))) uint4 s_img_all[4][512];  // per wave: the PosLines of its 64 reads (8 KB)
@@ -229,7 +229,28 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     }
     if (pending && !missed) ++other_n;
     // records leave as whole lines: a pending read's slot is written too (zeros) and overwritten by k_scatter_pending
-    if (valid) reinterpret_cast<uint4*>(a.out)[r] = make_uint4((uint32_t)e0, (uint32_t)(e0 >> 32), (uint32_t)e1, (uint32_t)(e1 >> 32));
+    if (kPlain) {
+      // 32-byte records (sm_emit's): a settled read is an interval of one row, or a read no record can hold
+      if (valid && !pending) {
+        const uint32_t meta = (uint32_t)(e1 >> 56);
+        sbwt_read_result res;
+        res.sa_lo = e0 & kPosMask;
+        res.sa_hi = res.sa_lo + (e0 >> kPosBits);
+        res.first_hit = (meta & R_NH) ? r : 0;
+        res.nh = (meta & R_NH) ? 1 : 0;
+        res.flags = ((meta >> R_FLAGS_SHIFT) & 3u) | ((meta & R_INVALID) ? kFlagInvalid : 0u);
+        a.results[r] = res;
+        if (meta & R_NH) {
+          sbwt_hit h;
+          h.pos0 = e1 & kPosMask;
+          h.chr_id = (uint32_t)(e1 >> kPosBits) & 0xFFFFu;
+          h.is_rc = (meta & R_RC) ? 1u : 0u;
+          a.hits[r] = h;
+        }
+      }
+    } else if (valid) {
+      reinterpret_cast<uint4*>(a.out)[r] = make_uint4((uint32_t)e0, (uint32_t)(e0 >> 32), (uint32_t)e1, (uint32_t)(e1 >> 32));
+    }
     const uint64_t pm = __ballot(pending);
     if (pm) {
       if (pending) s_pend[n_buf + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = (uint32_t)r;

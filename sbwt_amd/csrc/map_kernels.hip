@@ -205,7 +205,9 @@ struct sbwt_ctx : MapWork {
   uint32_t* d_pend_list = nullptr;  // max_reads entries
   uint32_t *d_pend_packed = nullptr, *d_pend_lens = nullptr;
   sbwt_compact_result* d_pend_out = nullptr;
-  uint64_t pend_words = 0, pend_lens_cap = 0, pend_out_cap = 0;
+  sbwt_read_result* d_pend_res = nullptr;  // 32-byte records and unique hits of the pending reads (sbwt_map_batch_device)
+  sbwt_hit* d_pend_hits = nullptr;
+  uint64_t pend_words = 0, pend_lens_cap = 0, pend_out_cap = 0, pend_res_cap = 0, pend_hits_cap = 0;
   hipEvent_t ev_s[2] = {nullptr, nullptr};
   uint32_t grid_settle = 0, grid_direct = 0;
   float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
@@ -309,7 +311,7 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_wave_info);
   hipFree(c->d_stacks);
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits); hipFree(c->d_wide);
-  hipFree(c->d_pend_list); hipFree(c->d_pend_packed); hipFree(c->d_pend_lens); hipFree(c->d_pend_out);
+  hipFree(c->d_pend_list); hipFree(c->d_pend_packed); hipFree(c->d_pend_lens); hipFree(c->d_pend_out); hipFree(c->d_pend_res); hipFree(c->d_pend_hits);
   for (int k = 0; k < 2; ++k)
     if (c->ev_s[k]) hipEventDestroy(c->ev_s[k]);
   for (int k = 0; k < 3; ++k)
@@ -365,12 +367,16 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
                     uint32_t words_per_read, int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits,
                     uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate,
                     float* ms_out, uint64_t* stats_out);
+static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads, uint32_t words_per_read,
+                            int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits, uint64_t hits_cap,
+                            uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate);
 static int map_pass(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
                     uint32_t words_per_read, int limit, int strand, sbwt_read_result* d_results, sbwt_hit* d_hits,
                     uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, bool accumulate) {
   const ResultIO io{d_results, nullptr, nullptr, 0};
-  return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, 0u, d_hits, hits_cap, multi_base,
-                  multi_used, nullptr, accumulate, c->last_ms, c->last_stats);
+  // (through the two-access fast pass where the index has what it needs, else the general kernels alone)
+  return map_pass_compact(c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, 0u, d_hits, hits_cap, multi_base, multi_used,
+                          nullptr, accumulate);
 }
 
 extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
@@ -441,7 +447,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     sa.wide_cap = io.wide_cap;
     sa.wide_count = &w.d_ctr->wide_count;
     sa.skip_hash = (mode & kModeSkipHash) ? 1u : 0u;
-    sa.hits = d_hits;
+    sa.hits = io.unique_hits ? io.unique_hits : d_hits;
     sa.hits_cap = hits_cap;
     sa.multi_queue = w.d_queue;
     sa.wave_info = w.d_wave_info;
@@ -578,9 +584,10 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
 template <typename T>
 static int ensure(T** p, uint64_t* have, uint64_t need);
 
-// One device pass with compact records.  Hits only, on an index whose hash slots carry text, records of 64 bases:
-// k_settle first (one access per read), then the general kernels over the reads it left pending, gathered into a
-// dense batch; otherwise the general kernels alone.
+// One device pass with a fast pass in front where the index allows one.  Compact records, hits only, on an index whose
+// hash slots carry text, records of 64 bases: k_settle first (one access per read), then the general kernels over the
+// reads it left pending, gathered into a dense batch; the other compact calls and the 32-byte records (io.compact
+// null): k_direct (two accesses); otherwise the general kernels alone.
 static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads, uint32_t words_per_read,
                             int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits, uint64_t hits_cap,
                             uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate) {
@@ -588,7 +595,8 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   // the fast passes need the text-carrying hash table; k_settle (one access) where the caller wants hits only and the
   // records hold 64 bases, k_direct (two accesses) for the other compact calls with records of 64 or 128 bases
   const bool fast = d.hash_text && d.hash_order && c->d_pend_list && !getenv("SBWT_NO_SETTLE");
-  const bool settle = fast && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
+  const bool plain = io.compact == nullptr;
+  const bool settle = fast && !plain && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
   const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !getenv("SBWT_NO_DIRECT");
   if (!settle && !direct) {
     if (!accumulate) {
@@ -605,6 +613,8 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.strand = strand;
   sa.limit = (uint64_t)(int64_t)limit;
   sa.out = io.compact;
+  sa.results = io.results;
+  sa.hits = d_hits;
   sa.pending_list = c->d_pend_list;
   sa.pending_count = &c->d_ctr->pending_count;
   sa.index_accesses = &c->d_ctr->index_accesses;
@@ -619,7 +629,15 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
   if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   else if (settle) k_settle<false><<<grid, 256, 0, c->stream>>>(d, sa);
-  else if (c->sort_lds_bytes) {
+  else if (plain && c->sort_lds_bytes) {
+    if (words_per_read == 4) k_direct<1, true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+    else if (words_per_read == 8) k_direct<2, true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+    else k_direct<3, true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  } else if (plain) {
+    if (words_per_read == 4) k_direct<1, false, true><<<grid, 256, 0, c->stream>>>(d, sa);
+    else if (words_per_read == 8) k_direct<2, false, true><<<grid, 256, 0, c->stream>>>(d, sa);
+    else k_direct<3, false, true><<<grid, 256, 0, c->stream>>>(d, sa);
+  } else if (c->sort_lds_bytes) {
     if (words_per_read == 4) k_direct<1, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
     else if (words_per_read == 8) k_direct<2, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
     else k_direct<3, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
@@ -649,17 +667,26 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
       if (int e = ensure(&c->d_pend_lens, &c->pend_lens_cap, want)) return e;
       if (int e = ensure(&c->d_pend_out, &c->pend_out_cap, want)) return e;
     }
+    if (plain && c->pend_res_cap < n_pending) {
+      const uint64_t want = std::min<uint64_t>(c->max_reads, n_pending + (n_pending >> 2));
+      if (int e = ensure(&c->d_pend_res, &c->pend_res_cap, want)) return e;
+      if (int e = ensure(&c->d_pend_hits, &c->pend_hits_cap, want)) return e;
+    }
     k_gather_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(d_packed, d_lens, c->d_pend_list, n_pending, words_per_read / 4,
                                                                          c->d_pend_packed, c->d_pend_lens);
     SBWT_LAUNCHED();
-    const ResultIO io2{nullptr, c->d_pend_out, io.wide, io.wide_cap};
+    const ResultIO io2 = plain ? ResultIO{c->d_pend_res, nullptr, nullptr, 0, c->d_pend_hits} : ResultIO{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
     uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
     if (rc != SBWT_OK && rc != SBWT_ERR_CAPACITY) return rc;
-    k_scatter_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(c->d_pend_out, c->d_pend_list, n_pending, io.compact);
+    if (plain)
+      k_scatter_pending_plain<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(c->d_pend_res, c->d_pend_hits, c->d_pend_list, n_pending,
+                                                                                 io.results, d_hits);
+    else
+      k_scatter_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(c->d_pend_out, c->d_pend_list, n_pending, io.compact);
     SBWT_LAUNCHED();
     SBWT_HIP(hipStreamSynchronize(c->stream));
     ms_pending = ms3[0];

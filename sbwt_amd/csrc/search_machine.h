@@ -84,6 +84,7 @@ struct ResultIO {
   sbwt_compact_result* compact;  // null: results[]
   sbwt_wide_result* wide;
   uint64_t wide_cap;
+  sbwt_hit* unique_hits = nullptr;  // results[]: where hits[read index] of the unique hits goes (null: the hits buffer of the call)
 };
 struct MultiRead {
   uint64_t lo, hi, first_hit;

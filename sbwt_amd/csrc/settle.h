@@ -29,6 +29,8 @@ struct SettleArgs {
   int strand;
   uint64_t limit;
   sbwt_compact_result* out;
+  sbwt_read_result* results;            // k_direct<.., kPlain>: 32-byte records instead of `out`, the hit of a settled read at
+  sbwt_hit* hits;                       // hits[its own index] (sbwt_map_batch_device)
   uint32_t* pending_list;               // read indices left to the general kernels
   unsigned long long* pending_count;
   unsigned long long* index_accesses;   // += 128-byte lines of the index read
@@ -264,6 +266,22 @@ __global__ __launch_bounds__(256) void k_gather_pending(const uint32_t* __restri
   for (uint32_t k = 0; k < pieces; ++k)
     reinterpret_cast<uint4*>(packed2)[i * pieces + k] = reinterpret_cast<const uint4*>(packed)[(uint64_t)r * pieces + k];
   lens2[i] = lens[r];
+}
+
+// the same for 32-byte records: a unique hit lives at its read's own index, in the pending batch (hits_from) as in
+// the caller's (hits); the lists of multi-hit reads are where the caller's first_hit already points
+__global__ __launch_bounds__(256) void k_scatter_pending_plain(const sbwt_read_result* __restrict__ from, const sbwt_hit* __restrict__ hits_from,
+                                                               const uint32_t* __restrict__ list, uint64_t n_pending,
+                                                               sbwt_read_result* __restrict__ out, sbwt_hit* __restrict__ hits) {
+  const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pending) return;
+  sbwt_read_result res = from[i];
+  const uint32_t r = list[i];
+  if (res.nh == 1 && res.first_hit == i) {  // (a list of one hit starts behind the slots of all reads: never at i)
+    hits[r] = hits_from[i];
+    res.first_hit = r;
+  }
+  out[r] = res;
 }
 
 __global__ __launch_bounds__(256) void k_scatter_pending(const sbwt_compact_result* __restrict__ from, const uint32_t* __restrict__ list,

@@ -354,6 +354,48 @@ def test_two_access_fast_pass_reports_intervals(world, monkeypatch, lens_):
     monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
 
 
+@pytest.mark.parametrize("lens_", [[32, 36, 50, 64], [65, 100, 128], [129, 150, 192]])
+def test_32_byte_records_take_the_two_access_fast_pass(world, monkeypatch, lens_):
+    """sbwt_map_batch / sbwt_map_batch_device (32-byte records, the unique hit at hits[read index]) go through k_direct
+    too: the settled reads' records and hits are written in place, the pending reads' by k_scatter_pending_plain.
+    Every field equals the oracle's and what the general kernels alone produce, on one call and on sub-batches"""
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 12000, lens_, mutate=0.3)
+    for f in fam[:10]:
+        reads.append(bytes(b"ACGT"[c] for c in f) * 2)      # 60 bases, multi-hit prefix
+        reads.append(bytes(b"ACGT"[c] for c in f))          # 30 bases, 2..1500 hits
+    packed, lens = sb.pack_reads(reads)
+    for limit, strand, subbatch in ((1000, 2, None), (0, 2, None), (1000, 0, None), (5, 1, "4096")):
+        lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand, nthreads=8)
+        outs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SBWT_NO_DIRECT", "1")
+            else:
+                monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
+            if subbatch:
+                monkeypatch.setenv("SBWT_SUBBATCH", subbatch)
+            ctx = sb.Context(ix, len(reads))
+            res, hits = ctx.map_batch(packed, lens, limit=limit, strand=strand)
+            t, st = ctx.last_timing_ex(), ctx.last_stats_ex()
+            ctx.close()
+            monkeypatch.delenv("SBWT_SUBBATCH", raising=False)
+            assert (t[3] > 0) == (not off)                     # the fast pass ran, or was switched off
+            if not off and max(lens_) <= 128:
+                assert st[7] < 0.5 * len(reads)                # ... and settled most reads
+            np.testing.assert_array_equal(res["sa_lo"], lo)
+            np.testing.assert_array_equal(res["sa_hi"], hi)
+            np.testing.assert_array_equal(res["nh"], nh)
+            uniq = nh == 1
+            k = np.maximum(nh, 0)
+            gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+            outs.append((res, uniq))
+        np.testing.assert_array_equal(outs[0][0]["flags"], outs[1][0]["flags"])
+    monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
+
+
 def test_roofline_probes_run(world):
     """sbwt_probe_random_access / sbwt_probe_gather_stream: measurement entry points; here only that they run on a small
     index and report a rate"""
