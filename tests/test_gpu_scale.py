@@ -261,6 +261,54 @@ def test_crowded_hash_table_groups_of_buckets(world, env):
         ix.close()
 
 
+def every_prefix_check(sb, ix, H, monkeypatch):
+    """EVERY string of H bases as a read of H bases, hits only: the fast pass (located prefixes, markers, misses that
+    prove absence, full groups) against the general kernels alone -- same NH, flags and hits for all 4^H of them"""
+    N = 4 ** H
+    packed = np.zeros((N, 4), dtype=np.uint32)
+    packed[:, 0] = np.arange(N, dtype=np.uint32)               # base t of read v = (v >> 2t) & 3
+    lens = np.full(N, H, dtype=np.uint32)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("SBWT_NO_SETTLE", "1")
+        else:
+            monkeypatch.delenv("SBWT_NO_SETTLE", raising=False)
+        ctx = sb.Context(ix, N)
+        rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=sb.MAP_HITS_ONLY)
+        st, t = ctx.last_stats_ex(), ctx.last_timing_ex()
+        ctx.close()
+        res, hits = sb.compact_expand(rec, lists, wide)
+        del rec
+        outs.append((res, hits, st, t))
+    monkeypatch.delenv("SBWT_NO_SETTLE", raising=False)
+    (ra, ha, sa, ta), (rb, hb, stb, tb) = outs
+    assert ta[3] > 0 and tb[3] == 0                            # with the fast pass; without
+    np.testing.assert_array_equal(ra["nh"], rb["nh"])
+    np.testing.assert_array_equal(ra["flags"], rb["flags"])
+    k = np.maximum(ra["nh"], 0).astype(np.int64)
+    within = np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k)
+    ga = np.repeat(ra["first_hit"].astype(np.int64), k) + within
+    gb = np.repeat(rb["first_hit"].astype(np.int64), k) + within
+    assert np.array_equal(ha[ga], hb[gb])
+    return ra, sa
+
+
+def test_every_possible_prefix_fast_pass_equals_general_kernels(world, monkeypatch):
+    """an order-13 hash table over this genome (6 x 10^6 rows, 4^13 = 6.7 x 10^7 possible prefixes, one in twelve
+    occurs): all 4^13 reads.  What a miss in the complete table proves is thereby checked for every prefix there is"""
+    sb, ix0, oix, codes, fam, rng = world
+    ix, _ = build_index(sb, codes, {"SBWT_HASH_ORDER": "13"})
+    try:
+        assert ix.info().hash_order == 13
+        res, st = every_prefix_check(sb, ix, 13, monkeypatch)
+        absent = int(((res["nh"] == 0) & (res["flags"] == 0)).sum())
+        assert 0.9 * absent < st[10] <= absent                  # nearly every read that maps nowhere was settled by a miss
+        assert int((res["nh"] > 0).sum()) > 4_000_000
+    finally:
+        ix.close()
+
+
 def test_reads_with_one_interval_share_a_located_list(world, monkeypatch):
     """small-RNA batches hold the same molecule many times: reads with the same interval and length are located once
     and the records of the others point at that list.  Same NH and lists as the oracle, which locates every read;
