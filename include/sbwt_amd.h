@@ -120,6 +120,8 @@ int sbwt_index_from_tables(int device, uint64_t interval, uint64_t n, uint64_t f
                            const uint64_t *chr_start, const char *const *chr_names, uint64_t n_npos,
                            const uint64_t *npos_key, const uint64_t *npos_val, sbwt_index **out);
 
+/* Frees the index and its device memory.  Every sbwt_ctx created on it must have been freed before: a ctx reads its
+ * index until sbwt_ctx_free returns. */
 void sbwt_index_free(sbwt_index *ix);
 int sbwt_index_get_info(const sbwt_index *ix, sbwt_index_info *info);
 /* chromosome name i (Aligner_table::chr_start_pos values); NULL when out of range */
@@ -159,7 +161,7 @@ int sbwt_host_tables_save(const sbwt_host_tables *t, const char *table_path);
 
 /* ---- mapping ----------------------------------------------------------------------------- */
 
-/* One worker: a HIP stream plus scratch sized for batches of up to max_reads reads. */
+/* One worker: a HIP stream plus scratch sized for batches of up to max_reads reads.  Free it before its index. */
 int sbwt_ctx_create(const sbwt_index *ix, uint64_t max_reads, sbwt_ctx **out);
 void sbwt_ctx_free(sbwt_ctx *ctx);
 

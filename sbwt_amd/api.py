@@ -3,6 +3,7 @@ import ctypes as C
 import importlib.util
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -256,6 +257,7 @@ class Index:
 
     def __init__(self, handle):
         self._h = handle
+        self._contexts = weakref.WeakSet()   # a ctx must not outlive its index (sbwt_ctx_free reads it): closed first
 
     @classmethod
     def load(cls, prefix, device=0):
@@ -321,6 +323,8 @@ class Index:
 
     def close(self):
         if self._h:
+            for ctx in list(self._contexts):
+                ctx.close()
             lib().sbwt_index_free(self._h)
             self._h = None
 
@@ -338,6 +342,7 @@ class Context:
         self.index = index
         self._h = C.c_void_p()
         _check(lib().sbwt_ctx_create(index._h, int(max_reads), C.byref(self._h)))
+        index._contexts.add(self)
 
     def map_batch(self, packed, lens, limit=1000, strand=2, hits_cap=None, out=None):
         """Host-buffer entry point. Returns (results structured array, hits structured array).

@@ -844,7 +844,7 @@ static int check_gfx950(int device) {
     return SBWT_ERR_HIP;
   }
   if (device < 0 || device >= count) { set_error("device ordinal out of range"); return SBWT_ERR_ARG; }
-  SBWT_HIP(hipSetDevice(device));
+  SBWT_HIP(enter_device(device));
   return SBWT_OK;
 }
 

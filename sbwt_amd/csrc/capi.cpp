@@ -55,7 +55,7 @@ static int check_device(int device) {
     set_error(std::string("device is ") + prop.gcnArchName + ", the kernels are built for gfx950 only");
     return SBWT_ERR_HIP;
   }
-  SBWT_HIP(hipSetDevice(device));
+  SBWT_HIP(enter_device(device));
   return SBWT_OK;
 }
 

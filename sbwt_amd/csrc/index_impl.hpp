@@ -34,6 +34,15 @@ __device__ __forceinline__ uint64_t global_thread() { return global_block() * bl
 // a failed launch must not go unnoticed until some later call happens to report it
 #define SBWT_LAUNCHED() SBWT_HIP(hipGetLastError())
 
+// Every entry point starts here: the device of its index, and a clean error slate -- hipGetLastError() reports the last
+// failure of ANY earlier runtime call on this thread, the caller's own included, and SBWT_LAUNCHED must not mistake one
+// for a failed launch of ours.
+inline hipError_t enter_device(int device) {
+  const hipError_t e = hipSetDevice(device);
+  (void)hipGetLastError();
+  return e;
+}
+
 // device temporary, freed on every way out of its scope (release() frees it early)
 template <typename T>
 struct DevTemp {

@@ -248,7 +248,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     set_error("sbwt_ctx_create: bad argument (max_reads must be in 1..2^32-1)");
     return SBWT_ERR_ARG;
   }
-  SBWT_HIP(hipSetDevice(ix->device));
+  SBWT_HIP(enter_device(ix->device));
   sbwt_ctx* c = new (std::nothrow) sbwt_ctx;
   if (!c) return SBWT_ERR_NOMEM;
   c->ix = ix;
@@ -401,7 +401,7 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
     if (n_hits_host) *n_hits_host = n_reads;
     return SBWT_ERR_CAPACITY;
   }
-  SBWT_HIP(hipSetDevice(c->ix->device));
+  SBWT_HIP(enter_device(c->ix->device));
   uint64_t multi_used = 0;
   const int rc = map_pass(c, d_packed, d_lens, n_reads, words_per_read, limit, strand, d_results, d_hits, hits_cap, n_reads,
                           &multi_used, false);
@@ -721,7 +721,7 @@ extern "C" int sbwt_map_batch_device_compact(sbwt_ctx* c, const uint32_t* d_pack
   }
   if (counts_host) counts_host[0] = counts_host[1] = 0;
   if (n_reads == 0) return SBWT_OK;
-  SBWT_HIP(hipSetDevice(c->ix->device));
+  SBWT_HIP(enter_device(c->ix->device));
   const ResultIO io{nullptr, d_out, d_wide, wide_cap};
   uint64_t multi_used = 0, wide_used = 0;
   const int rc = map_pass_compact(c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, 0,
@@ -772,7 +772,7 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
   }
   if (n_hits) *n_hits = 0;
   if (n_reads == 0) return SBWT_OK;
-  SBWT_HIP(hipSetDevice(c->ix->device));
+  SBWT_HIP(enter_device(c->ix->device));
   const uint64_t words = n_reads * words_per_read;
   uint64_t lens_have = c->staged_reads, res_have = c->staged_reads;
   if (int rc = ensure(&c->d_packed, &c->staged_words, words)) return rc;
@@ -885,7 +885,7 @@ int sbwt::static_scratch_setup(int device) {
   if (device < 0 || device >= kMaxDevices) return SBWT_OK;  // such a device simply has no static path
   std::lock_guard<std::mutex> lk(g_static_mutex);
   if (g_scratch_ptr[device]) return SBWT_OK;
-  SBWT_HIP(hipSetDevice(device));
+  SBWT_HIP(enter_device(device));
   unsigned char* ptr = nullptr;
   SBWT_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
   if (!ptr) {
@@ -901,7 +901,7 @@ int sbwt::static_scratch_setup(int device) {
 
 int sbwt::finish_index(sbwt_index* ix) {
   if (int rc = static_scratch_setup(ix->device)) return rc;
-  SBWT_HIP(hipSetDevice(ix->device));
+  SBWT_HIP(enter_device(ix->device));
   MapWork w;
   SBWT_HIP(plan_launches(ix, &w));
   ix->plan.grid_sm_lds = w.grid_sm_lds;
@@ -952,7 +952,7 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
     set_error("sbwt_map_batch_device_static: the static scratch of this device was not set up");
     return SBWT_ERR_HIP;
   }
-  SBWT_HIP(hipSetDevice(dev));
+  SBWT_HIP(enter_device(dev));
   MapWork w;
   w.stream = static_cast<hipStream_t>(stream);
   w.d_ctr = reinterpret_cast<Counters*>(base + kStaticOffCtr);
@@ -1009,7 +1009,7 @@ extern "C" int sbwt_map_batch_compact(sbwt_ctx* c, const uint32_t* packed, const
   }
   if (counts) counts[0] = counts[1] = 0;
   if (n_reads == 0) return SBWT_OK;
-  SBWT_HIP(hipSetDevice(c->ix->device));
+  SBWT_HIP(enter_device(c->ix->device));
   // staging: the 32-byte result staging of the plain entry point holds two compact records per slot
   const uint64_t words = n_reads * words_per_read;
   uint64_t lens_have = c->staged_reads, res_have = c->staged_reads;

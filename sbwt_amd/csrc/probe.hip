@@ -95,7 +95,7 @@ extern "C" int sbwt_probe_gather_stream(const sbwt_index* ix, uint64_t n_accesse
     set_error("sbwt_probe_gather_stream: bad argument");
     return SBWT_ERR_ARG;
   }
-  SBWT_HIP(hipSetDevice(ix->device));
+  SBWT_HIP(enter_device(ix->device));
   const void* table = ix->d.hash_tab ? (const void*)ix->d.hash_tab : (const void*)ix->d.sa_full;
   const uint64_t bytes = ix->d.hash_tab ? ix->d.hash_buckets * ((ix->d.hash_text ? 16ull : 8ull) * kHashSlots) : ix->d.n * 8ull;
   const uint64_t n_lines = bytes / 128;
@@ -152,7 +152,7 @@ extern "C" int sbwt_probe_random_access(const sbwt_index* ix, uint32_t chains_pe
     set_error("sbwt_probe_random_access: bad argument (chains_per_lane is 1, 2 or 4)");
     return SBWT_ERR_ARG;
   }
-  SBWT_HIP(hipSetDevice(ix->device));
+  SBWT_HIP(enter_device(ix->device));
   const void* table = ix->d.hash_tab ? (const void*)ix->d.hash_tab : (const void*)ix->d.sa_full;
   const uint64_t bytes = ix->d.hash_tab ? ix->d.hash_buckets * ((ix->d.hash_text ? 16ull : 8ull) * kHashSlots) : ix->d.n * 8ull;
   const uint64_t n_lines = bytes / 128;
