@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
   constexpr uint32_t kMaxLen = 64u * kPieces;
   const uint4* const recs = reinterpret_cast<const uint4*>(a.packed);
   const uint4* const tab = reinterpret_cast<const uint4*>(ix.hash_tab);
+  static_assert(sizeof(s_img_all[0]) / sizeof(uint4) >= kBktLds, "settle_lookup stages its buckets in the wave's image buffer");
   uint4* const s_img = s_img_all[threadIdx.x >> 6];
   uint32_t* const s_pend = s_pend_all[threadIdx.x >> 6];
   uint32_t n_buf = 0;  // wave-uniform
