@@ -186,7 +186,8 @@ int sbwt_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t n_reads,
  * limit / strand are `sbwt map -m / -s` (main.cpp:167-168).
  * Layout of hits[]: the hit of a read with exactly one surviving hit lives at the read's own index
  * (first_hit == read index), so hits_cap must be at least n_reads; the lists of multi-hit reads follow behind
- * the first n_reads slots, each contiguous and in upstream emission order (first_hit says where).  Multi-hit reads
+ * the first n_reads slots, each contiguous and in upstream emission order (first_hit says where; the ORDER of the lists
+ * behind the first n_reads slots is not part of the contract and may differ from call to call).  Multi-hit reads
  * of one batch with the same SA interval and length have the same list (upstream would compute it once per read,
  * searcher.hpp:424-503): it is located once and their records carry the SAME first_hit, so lists may alias --
  * treat hits[] as read-only per read.  Slots of reads without a hit, and the slots reserved for reads that share
