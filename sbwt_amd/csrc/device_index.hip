@@ -686,7 +686,7 @@ __global__ __launch_bounds__(64) void k_hash_cover(DeviceIndex ix, uint32_t K, u
   const uint64_t vv = hash_mix(v, K);
   const uint64_t tag = vv & ((1ull << tag_bits) - 1ull);
   // already there?  (a row of an interval whose first row stored the marker; markers of the same K-mer written by
-  // two threads of this kernel are equal, which the lookups tolerate: they OR what carries the tag)
+  // two threads of this kernel are equal words, so a lookup that meets both reads the same thing twice)
   const uint64_t bkt = __umul64hi(vv << (64 - 2 * K), n_buckets);
   for (uint32_t s = 0; s < group * kHashSlots; ++s) {
     const uint64_t w = tab[((bkt ^ (uint64_t)(s / kHashSlots)) * kHashSlots + (s & (kHashSlots - 1))) * 2u];
