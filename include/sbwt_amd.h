@@ -220,14 +220,17 @@ int sbwt_compact_expand(const sbwt_compact_result *compact, uint64_t n_reads, co
                         sbwt_hit *hits);
 
 /* sbwt_map_batch_device for callers that cannot allocate.  No counterpart upstream (its per-read vectors live on
- * the host heap, searcher.hpp:419-422); it exists for callers that must not reach hipMalloc: code under HIP graph
- * capture, tight serving loops, harnesses that forbid allocation.  No sbwt_ctx: the scratch of the kernels
+ * the host heap, searcher.hpp:419-422); it exists for callers that must not reach hipMalloc: tight serving loops,
+ * harnesses that forbid allocation, code that runs between the captures of a HIP graph.  (The call itself cannot be
+ * captured INTO a graph: it synchronises `stream` and reads its counters back on the host to report n_hits and
+ * SBWT_ERR_CAPACITY.)  No sbwt_ctx: the scratch of the kernels
  * (counters, the two read queues, per-wave totals, the depth-first stacks: 14.1 MiB) is a file-scope device array
  * that every GPU the library runs on holds until the process ends; its address and a 64-byte pinned read-back
  * buffer are set up per device by the call that creates an index there.  This call itself allocates and frees
  * nothing (no hipMalloc / hipFree / stream or event creation), on `stream` (a hipStream_t; NULL = the default
- * stream), which it synchronises before returning.  Same arguments, results, hits layout and error codes as
- * sbwt_map_batch_device; at most 1,048,576 reads per call (SBWT_ERR_ARG beyond); no kernel timing
+ * stream), which it synchronises before returning.  Same arguments, per-read records, per-read hit lists and error
+ * codes as sbwt_map_batch_device (WHERE a list lies behind the first n_reads slots may differ: this path has no
+ * grouping table, so reads with one interval get a list each instead of sharing one); at most 1,048,576 reads per call (SBWT_ERR_ARG beyond); no kernel timing
  * (sbwt_ctx_last_timing / _stats have no counterpart here).  All calls on one GPU share that GPU's array: calls that
  * overlap on one GPU race; calls on different GPUs, and sbwt_ctx calls beside it, do not interfere. */
 int sbwt_map_batch_device_static(const sbwt_index *ix, void *stream, const uint32_t *d_packed,

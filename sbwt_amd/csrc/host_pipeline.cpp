@@ -385,9 +385,15 @@ struct BatchSlot {
 
 extern "C" int sbwt_map_fastq_multi(const sbwt_index* const* ixs, int n_ix, const char* fastq_path, const char* sam_path, int limit,
                                     int strand, int n_threads, uint64_t stats[5]) {
-  if (!ixs || n_ix < 1 || !fastq_path || !sam_path) return SBWT_ERR_ARG;
+  if (!ixs || n_ix < 1 || !fastq_path || !sam_path) {
+    set_error("sbwt_map_fastq_multi: null pointer, or no index to map against (n_ix < 1)");
+    return SBWT_ERR_ARG;
+  }
   for (int d = 0; d < n_ix; ++d) {
-    if (!ixs[d]) return SBWT_ERR_ARG;
+    if (!ixs[d]) {
+      set_error("sbwt_map_fastq_multi: null index");
+      return SBWT_ERR_ARG;
+    }
     if (ixs[d]->d.n != ixs[0]->d.n || ixs[d]->chr.names != ixs[0]->chr.names) {
       set_error("sbwt_map_fastq_multi: the indexes are not replicas of one index");
       return SBWT_ERR_ARG;
@@ -432,6 +438,12 @@ extern "C" int sbwt_map_fastq_multi(const sbwt_index* const* ixs, int n_ix, cons
   for (int d = 0; d < n_ix && rc == SBWT_OK; ++d) {
     lanes[(size_t)d].ix = ixs[d];
     rc = sbwt_ctx_create(ixs[d], batch, &lanes[(size_t)d].ctx);
+  }
+  if (rc != SBWT_OK) {  // a ctx could not be made: sbwt_ctx_create has set the message; nothing of the file is read
+    for (auto& L : lanes)
+      if (L.ctx) sbwt_ctx_free(L.ctx);
+    if (!to_stdout) fclose(out);
+    return rc;
   }
   const char* p = fq.data() ? reinterpret_cast<const char*>(fq.data()) : nullptr;
   const uint64_t fsize = p ? fq.size() : 0;
@@ -629,7 +641,7 @@ extern "C" int sbwt_map_fastq_multi(const sbwt_index* const* ixs, int n_ix, cons
       if (final_rc != SBWT_OK) rc = final_rc;
       if (tick >= 3 && tick - 3 + 1 >= last) break;  // the last batch has been written
     }
-    if (rc != SBWT_OK) set_error(final_err);
+    if (final_rc != SBWT_OK) set_error(final_err);
     for (const auto& s5 : share_stats)
       for (int k = 0; k < 5; ++k) st[k] += s5[(size_t)k];
     if (rc == SBWT_OK && stop_after != ~0ull) {

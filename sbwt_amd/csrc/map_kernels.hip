@@ -186,7 +186,16 @@ struct MapWork {
   uint32_t* d_group_leader = nullptr;
   uint32_t group_slots = 0;                   // a power of two; 0: no grouping (the no-allocation entry point)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // null: the pass is not timed
+  // test knobs (environment variables, read ONCE: when the ctx is made, or -- the entry point without a ctx -- the index)
+  bool no_bfs = false;
+  uint32_t ring_width_max = (uint32_t)kRingWidthMax, ring_chr_max = 0xFFFFu;
 };
+
+static void read_pass_knobs(bool* no_bfs, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
+  *no_bfs = getenv("SBWT_NO_BFS") != nullptr;
+  *ring_width_max = debug_knob("SBWT_DEBUG_RING_WIDTH", (uint32_t)kRingWidthMax);
+  *ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
+}
 
 struct sbwt_ctx : MapWork {
   const sbwt_index* ix = nullptr;
@@ -211,6 +220,8 @@ struct sbwt_ctx : MapWork {
   hipEvent_t ev_s[2] = {nullptr, nullptr};
   uint32_t grid_settle = 0, grid_direct = 0;
   float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
+  bool no_settle = false, no_direct = false;  // test knobs, read when the ctx is made
+  uint64_t subbatch = 2u << 20;               // reads per sub-batch of the host-buffer entry points (SBWT_SUBBATCH; 0 = never split)
 };
 
 // Launch shapes of the kernels for this index on its device: resident workgroups per kernel variant and the LDS
@@ -253,6 +264,10 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (!c) return SBWT_ERR_NOMEM;
   c->ix = ix;
   c->max_reads = max_reads;
+  read_pass_knobs(&c->no_bfs, &c->ring_width_max, &c->ring_chr_max);
+  c->no_settle = getenv("SBWT_NO_SETTLE") != nullptr;
+  c->no_direct = getenv("SBWT_NO_DIRECT") != nullptr;
+  if (const char* sb = getenv("SBWT_SUBBATCH")) c->subbatch = strtoull(sb, nullptr, 10);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&c->d_ctr, sizeof(Counters));
   if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, sizeof(Counters));
@@ -453,8 +468,8 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     sa.wave_info = w.d_wave_info;
     sa.index_accesses = &w.d_ctr->index_accesses;
     sa.hash_stats = w.d_ctr->hash_stats;
-    sa.ring_width_max = debug_knob("SBWT_DEBUG_RING_WIDTH", (uint32_t)kRingWidthMax);
-    sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
+    sa.ring_width_max = w.ring_width_max;
+    sa.ring_chr_max = w.ring_chr_max;
     const bool lds = w.sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
     const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? w.grid_sm_lds : w.grid_sm_glb);
@@ -514,7 +529,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
       k_multi_sort<256, false><<<w.grid_sort, 256, 0, w.stream>>>(d, ms);
     }
     SBWT_LAUNCHED();
-    if (!getenv("SBWT_NO_BFS")) {  // the same walk level by level, a team per read (multi_locate.h); k_multi takes what is left
+    if (!w.no_bfs) {  // the same walk level by level, a team per read (multi_locate.h); k_multi takes what is left
       k_multi_bfs<64, 64><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
       k_multi_bfs<256, 512><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
       k_multi_bfs<256, 1024><<<w.grid_bfs / 2, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);  // frontiers the second outgrew
@@ -594,10 +609,10 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const DeviceIndex& d = c->ix->d;
   // the fast passes need the text-carrying hash table; k_settle (one access) where the caller wants hits only and the
   // records hold 64 bases, k_direct (two accesses) for the other compact calls with records of 64 or 128 bases
-  const bool fast = d.hash_text && d.hash_order && c->d_pend_list && !getenv("SBWT_NO_SETTLE");
+  const bool fast = d.hash_text && d.hash_order && c->d_pend_list && !c->no_settle;
   const bool plain = io.compact == nullptr;
   const bool settle = fast && !plain && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
-  const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !getenv("SBWT_NO_DIRECT");
+  const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !c->no_direct;
   if (!settle && !direct) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
@@ -622,7 +637,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.pending_other = &c->d_ctr->pending_other;
   sa.absent_count = &c->d_ctr->absent_count;
   sa.lds_tables = c->sort_lds_bytes ? 1u : 0u;
-  sa.ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
+  sa.ring_chr_max = c->ring_chr_max;
   sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
   SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
@@ -783,8 +798,7 @@ extern "C" int sbwt_map_batch(sbwt_ctx* c, const uint32_t* packed, const uint32_
   // Large batches go in sub-batches so that the copy-in of the next one and the copy-out of the previous one run
   // while one is being mapped (the link, not the kernels, bounds this entry point).  SBWT_SUBBATCH = reads per
   // sub-batch (0 = never split).
-  uint64_t sub = 2u << 20;
-  if (const char* e = getenv("SBWT_SUBBATCH")) sub = strtoull(e, nullptr, 10);
+  uint64_t sub = c->subbatch;
   sub = (sub + 63) & ~63ull;  // whole result lines per sub-batch
   if (sub && n_reads >= 2 * sub && hits_cap >= n_reads && c->s_in && c->s_out) {
     uint64_t used_multi = 0;
@@ -911,6 +925,7 @@ int sbwt::finish_index(sbwt_index* ix) {
   ix->plan.sm_lds_bytes = w.sm_lds_bytes;
   ix->plan.sm_ring_bytes = w.sm_ring_bytes;
   ix->plan.sort_lds_bytes = w.sort_lds_bytes;
+  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
   return SBWT_OK;
 }
 
@@ -969,6 +984,9 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
   w.sm_lds_bytes = ix->plan.sm_lds_bytes;
   w.sm_ring_bytes = ix->plan.sm_ring_bytes;
   w.sort_lds_bytes = ix->plan.sort_lds_bytes;
+  w.no_bfs = ix->plan.no_bfs;
+  w.ring_width_max = ix->plan.ring_width_max;
+  w.ring_chr_max = ix->plan.ring_chr_max;
   if (!w.grid_sort || !w.sm_ring_bytes) {
     set_error("sbwt_map_batch_device_static: the index carries no launch plan");
     return SBWT_ERR_HIP;
@@ -1020,8 +1038,7 @@ extern "C" int sbwt_map_batch_compact(sbwt_ctx* c, const uint32_t* packed, const
   if (int rc = ensure(&c->d_hits, &c->staged_hits, hits_cap ? hits_cap : 1)) return rc;
   if (int rc = ensure(&c->d_wide, &c->staged_wide, wide_cap ? wide_cap : 1)) return rc;
   sbwt_compact_result* d_out = reinterpret_cast<sbwt_compact_result*>(c->d_results);
-  uint64_t sub = 2u << 20;
-  if (const char* e = getenv("SBWT_SUBBATCH")) sub = strtoull(e, nullptr, 10);
+  uint64_t sub = c->subbatch;
   sub = (sub + 63) & ~63ull;
   if (!sub || n_reads < 2 * sub || !c->s_in || !c->s_out) sub = n_reads;  // one piece
   uint64_t used_multi = 0, used_wide = 0;

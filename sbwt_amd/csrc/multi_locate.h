@@ -560,13 +560,16 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     }
     team_sync<T>();
     SBWT_PHASE(0);
+    // (the overflow flag is read where every thread of the team sees the same value: between two syncs, like n_cur --
+    // a wave ahead of the others may set it for the NEXT level while they still evaluate the loop condition)
+    bool over = false;
     // Level d: the nodes of depth d are scanned for sampled rows AND expanded into the nodes of depth d + 1, by
     // different threads at the same time -- a node's own scan is not needed to expand it, except that a node of one
     // sampled row has no children (searcher.hpp:495): its scan marks it, and the children made meanwhile are dropped
     // at the next level.  So a level costs the longer of the two dependent chains (rank query; bitmap -> sampled
     // position), not their sum.
     uint32_t n_cur = 1, cur = 0;
-    for (uint32_t d = 0; d < ix.interval && n_cur && !cnt[2]; ++d) {
+    for (uint32_t d = 0; d < ix.interval && n_cur && !over; ++d) {
       const uint64_t *cfe = fr + cur * 3u * kNodes, *c0 = cfe + kNodes, *c1 = cfe + 2 * kNodes;
       uint64_t *xfe = fr + (cur ^ 1u) * 3u * kNodes, *x0 = xfe + kNodes, *x1 = xfe + 2 * kNodes;
       const uint8_t* dead_of = pruned + ((d + 2u) % 3u) * kNodes;  // marks of depth d - 1
@@ -674,6 +677,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
       SBWT_PHASE(1);
       team_sync<T>();
       n_cur = cnt[1] < kNodes ? cnt[1] : kNodes;
+      over = cnt[2] != 0;
       team_sync<T>();
       if (tid == 0) { cnt[1] = 0; if (T == 256) s_nbig[d & 1u] = 0; }
       cur ^= 1;
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
       if (tid == 0) s_phase[team][11] += 1;
 #endif
     }
-    if (cnt[2]) continue;  // outgrew the team: the read stays queued for k_multi
+    if (over) continue;  // outgrew the team: the read stays queued for k_multi (team-uniform: snapshotted between syncs)
     const uint32_t H = cnt[0];
     // ---- emission order
     uint32_t N = 64;

@@ -119,11 +119,11 @@ extern "C" int sbwt_probe_gather_stream(const sbwt_index* ix, uint64_t n_accesse
     k_probe_stream<0><<<grid, 256>>>(static_cast<const uint4*>(table), n_lines, in, out, n_accesses < 4096 ? n_accesses : 4096);  // warm-up
     e = hipDeviceSynchronize();
   }
+  const char* ve = getenv("SBWT_PROBE_VARIANT");  // (tools/probe_variants.py: which streams run beside the gather; read before anything is timed)
+  const int variant = ve ? atoi(ve) : 0;
   for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {
     e = hipEventRecord(a, nullptr);
     {
-      const char* ve = getenv("SBWT_PROBE_VARIANT");
-      const int variant = ve ? atoi(ve) : 0;
       const uint4* t = static_cast<const uint4*>(table);
       if (variant == 1) k_probe_stream<1><<<grid, 256>>>(t, n_lines, in, out, n_accesses);
       else if (variant == 2) k_probe_stream<2><<<grid, 256>>>(t, n_lines, in, out, n_accesses);

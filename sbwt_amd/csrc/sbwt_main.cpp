@@ -101,6 +101,8 @@ static int cmd_map(int argc, char** argv) {
           fastq.c_str(), prefix.c_str(), sam.c_str(), nthread, limit, strand);
   int n_dev = 0;
   if (sbwt_device_count(&n_dev) != SBWT_OK) { fprintf(stderr, "Error: %s\n", sbwt_last_error()); return 2; }
+  if (n_dev <= 0) { fprintf(stderr, "Error: no GPU found\n"); return 2; }
+  if (gpus > n_dev) fprintf(stderr, "Warning: -g %d asks for more GPUs than this machine shows (%d).\nSo reset -g=%d\n", gpus, n_dev, n_dev);
   if (gpus <= 0 || gpus > n_dev) gpus = n_dev;
   // one replica of the index per device, loaded side by side
   std::vector<sbwt_index*> ixs((size_t)gpus, nullptr);

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
   bool reserve = false;
   uint64_t flushed = range_begin;  // wave-uniform: results of reads below it are in global memory
   uint32_t tally = 0;              // random index accesses this lane needed (128-byte lines)
-  uint32_t tally_h = 0;            // hash_tab lookups (high half) and hits (low half) of this lane
+  uint32_t tally_hq = 0, tally_hh = 0;  // hash_tab lookups and hits of this lane (a lane of a 2^32-read batch makes more than 2^16)
   uint64_t wave_slots = 0;  // wave-uniform: hit slots handed to the multi-hit reads of this wave so far
   uint32_t wave_multi = 0;  // wave-uniform: how many such reads
   uint32_t L = 0, j = 0, aux = 0, flags = 0, nL = 0, mL = 0, pf = 0;
@@ -665,7 +665,8 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
       pf = (pf | PF_H1) & ~PF_RH1;
       const uint64_t run = (found & 0xFFFFFFull) >> ix.hash_tag_bits;
       if (run == 0) found = ~0ull;  // a marker (device_layout.h): the prefix occurs, but not as one located row
-      tally_h += 0x10000u + (found != ~0ull ? 1u : 0u);
+      tally_hq += 1u;
+      tally_hh += found != ~0ull ? 1u : 0u;
       if (found != ~0ull) {
         nk = kKmerLocated | (found >> 24) | (run << kPosBits);
         pf |= PF_K1 | PF_KH;
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
     for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
     if (lane == 0) atomicAdd(a.index_accesses, (unsigned long long)t);
     if (H) {  // wave-uniform
-      uint32_t q = tally_h >> 16, h = tally_h & 0xFFFFu;
+      uint32_t q = tally_hq, h = tally_hh;
       for (int d = 32; d > 0; d >>= 1) { q += __shfl_xor(q, d); h += __shfl_xor(h, d); }
       if (lane == 0) { atomicAdd(a.hash_stats, (unsigned long long)q); atomicAdd(a.hash_stats + 1, (unsigned long long)h); }
     }
