@@ -3,16 +3,21 @@
 
 Workload (BASELINE.json configs[2]): synthetic genome of 2.94 G non-N bases over 24 contigs with
 GRCh38-like lengths and N runs, 100 M error-free 50-bp reads, both strands, resident in HBM.
-One step = one pass of the hot path (sbwt_map_batch_device) over the whole read batch.
+One step = one pass of the hot path (sbwt_map_batch_device[_compact]) over the whole read batch.
 N > 1: one process per GPU, index replicated, each rank maps its own 100 M reads (weak scaling, no
 data-path collective; torch.distributed/RCCL only for the barrier and the max-over-ranks).  `--gpus N` without
 a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child processes, before this
 process touches a GPU; under torchrun each process is one rank.
 
-Other workloads (parity-checked side lines, never the headline): --rank-path (no memoised search prefix:
-SBWT_HASH_ORDER=0 SBWT_KMER_ORDER=12, the backward search through rank queries that north_star names),
---genome repeats (40 % of the bases in diverged repeat families + exact segmental duplications),
---shuffle-ties (suffix order stopped at sort_len 256 with ties in arbitrary order, as upstream's sort leaves them).
+The default single-GPU run also measures, in the same process and after the headline's timed region, the other
+configurations of BASELINE.json and of DESIGN.md section 4 (`configs` in the JSON line: the interval-reporting
+layouts, 100-bp reads, the dm6-sized index, the small-RNA workload, the repeat-rich genome on a fully sorted and on
+a tie-shuffled index, the rank path, the index written to files and loaded back) -- each with its own index where it
+needs one, each checked against the oracle.  `--no-configs` skips them; any workload flag selects ONE workload as the
+headline instead (side lines for the profiling scripts, never the driver's number).
+
+`--config 4` is BASELINE.json configs[3] as a STRONG-scaling run: a fixed total of 800 M x 100-bp reads cut into
+contiguous shares by sbwt_shard_range, every rank mapping its share chunk by chunk from HBM.
 
 Prints ONE JSON line on rank 0.  torch is plumbing here (device memory for the synthetic inputs,
 barrier); the timed work is the library's HIP kernels behind the C ABI.
@@ -93,6 +98,8 @@ def plant_repeats(torch, dev, codes, g, seed, n_families=2000, max_copies=5000):
     u = torch.rand(n_families, device=dev, generator=gen)
     copies = torch.exp(u * float(np.log(max_copies / 2.0))).mul(2.0).long().clamp(2, max_copies)
     total = int(copies.sum().item())
+    if total > g // 64 - 2:
+        raise ValueError("plant_repeats: %d copies do not fit a genome of %d bases (a full-size workload)" % (total, g))
     slots = torch.randperm(g // 64 - 2, device=dev, generator=gen)[:total] * 64 + 7
     fam = torch.randint(0, 4, (n_families, 30), dtype=torch.uint8, device=dev, generator=gen)
     owner = torch.repeat_interleave(torch.arange(n_families, device=dev), copies)
@@ -335,6 +342,439 @@ def cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores):
                                              "source": "BASELINE.md (survey container, other host; not measured here)"}}
 
 
+class Workload:
+    """A synthetic genome and its index on one device.  The test knobs that shape an index (no memoised search prefix,
+    suffix order stopped at sort_len) are environment variables the library reads while it BUILDS the index: set for
+    the build, removed again."""
+
+    def __init__(self, torch, dev, sb, scale=1.0, genome="iid", plant=False, rank_path=False, shuffle_ties=False,
+                 want_tables=False):
+        self.torch, self.dev, self.sb = torch, dev, sb
+        self.scale, self.genome, self.plant, self.rank_path, self.shuffle_ties = scale, genome, plant, rank_path, shuffle_ties
+        t0 = time.time()
+        self.lens_chr, self.g, self.chr_start, self.npos_key, self.npos_val = synth_tables(scale)
+        self.codes, packed_genome = make_genome(torch, dev, self.g, seed=38)
+        self.slots = None
+        self.repeat_cover = None
+        if genome == "repeats":
+            self.repeat_cover = plant_repeat_families(torch, dev, self.codes, self.g, seed=40)
+            packed_genome = repack(torch, dev, self.codes, self.g)
+        if plant:
+            self.slots = plant_repeats(torch, dev, self.codes, self.g, seed=5)
+            packed_genome = repack(torch, dev, self.codes, self.g)
+        torch.cuda.synchronize()
+        self.t_genome = time.time() - t0
+        env = {}
+        if rank_path:
+            env.update(SBWT_HASH_ORDER="0", SBWT_KMER_ORDER="12")
+        if shuffle_ties:
+            env.update(SBWT_DEBUG_SORT_DEPTH="256")
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        t0 = time.time()
+        try:
+            self.ix, self.tables = sb.build_index_device(packed_genome.data_ptr(), self.g, self.chr_start, self.npos_key,
+                                                         self.npos_val, interval=64, device=dev.index, want_index=True,
+                                                         want_tables=want_tables)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        self.t_index = time.time() - t0
+        del packed_genome
+        self.info = self.ix.info()
+        self.many_hits = plant or genome == "repeats"
+        self._oix = None
+
+    def describe(self):
+        return "%s synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s%s)" % (
+            "GRCh38-sized" if self.scale == 1.0 else "%.4g x GRCh38-sized" % self.scale, self.g / 1e9,
+            ", planted repeat family" if self.plant else "",
+            ", %.0f %% of the bases in diverged repeat families + exact duplications" % (100 * self.repeat_cover)
+            if self.repeat_cover else "")
+
+    def oracle(self, oracle_lib):
+        if self._oix is None and self.tables is not None:
+            self._oix = oracle_index_from_tables(oracle_lib, self.tables, self.chr_start, self.npos_key, self.npos_val)
+        return self._oix
+
+    def drop_genome(self):
+        self.codes = None
+        self.slots = None
+        self.torch.cuda.empty_cache()
+
+    def close(self):
+        if self._oix is not None:
+            self._oix.close()
+            self._oix = None
+        if self.tables is not None:
+            self.sb.host_tables_free(self.tables)
+            self.tables = None
+        self.codes = None
+        self.slots = None
+        if self.ix is not None:
+            self.ix.close()
+            self.ix = None
+        self.torch.cuda.empty_cache()
+
+
+class Run:
+    """One measured pass configuration over one batch: output buffers, the timed steps, and the checks on what came back."""
+
+    def __init__(self, torch, dev, sb, wl, packed, lens, n_reads, L, wpr, layout, ctx=None):
+        self.torch, self.dev, self.sb, self.wl = torch, dev, sb, wl
+        self.packed, self.lens, self.n_reads, self.L, self.wpr, self.layout = packed, lens, n_reads, L, wpr, layout
+        self.compact = layout != "plain"
+        self.mode = sb.MAP_HITS_ONLY if layout == "hits" else 0
+        self.own_ctx = ctx is None
+        self.ctx = ctx if ctx is not None else sb.Context(wl.ix, n_reads)
+        self.wide_cap = 1 << 16
+        free_b, _ = torch.cuda.mem_get_info()
+        list_cap = int(min(80 * n_reads, max(1 << 20, (free_b - (6 << 30)) // 16)))      # room for the lists of multi-hit reads
+        if self.compact:
+            self.results = torch.empty(n_reads * 16, dtype=torch.uint8, device=dev)      # sbwt_compact_result[n_reads]
+            self.hits_cap = (1 << 20) if not wl.many_hits else list_cap                  # lists of multi-hit reads only
+            self.wide = torch.empty(self.wide_cap * 48, dtype=torch.uint8, device=dev)
+        else:
+            self.results = torch.empty(n_reads * 32, dtype=torch.uint8, device=dev)      # sbwt_read_result[n_reads]
+            self.hits_cap = n_reads + (1 << 20) if not wl.many_hits else n_reads + list_cap
+            self.wide = None
+        self.hits = torch.empty(self.hits_cap * 16, dtype=torch.uint8, device=dev)
+        self.kernel_ms = []
+        self.n_hits = self.n_wide = 0
+
+    def step(self):
+        if self.compact:
+            return self.ctx.map_batch_device_compact(self.packed.data_ptr(), self.lens.data_ptr(), self.n_reads, self.wpr,
+                                                     self.results.data_ptr(), self.hits.data_ptr(), self.hits_cap,
+                                                     self.wide.data_ptr(), self.wide_cap, limit=1000, strand=2, mode=self.mode)
+        return (self.ctx.map_batch_device(self.packed.data_ptr(), self.lens.data_ptr(), self.n_reads, self.wpr,
+                                          self.results.data_ptr(), self.hits.data_ptr(), self.hits_cap, limit=1000, strand=2), 0)
+
+    def timed(self, steps, warmup, dist=None):
+        from sbwt_amd import shard
+
+        def timed_step():
+            self.n_hits, self.n_wide = self.step()           # synchronises its own stream before returning
+            self.kernel_ms.append(self.ctx.last_timing_ex())  # HIP events on the ctx stream, around the kernels of this step
+
+        for _ in range(warmup):
+            self.step()
+        self.elapsed = shard.timed_steps(timed_step, steps, 0, dist=dist, sync=self.torch.cuda.synchronize, device=self.dev)
+        self.steps = steps
+        self.stats = self.ctx.last_stats_ex()
+        return self.elapsed
+
+    def decode(self):
+        """the records in the plain layout (device tensors), whatever layout the call wrote: only for the checks"""
+        torch, dev, n_reads = self.torch, self.dev, self.n_reads
+        if self.compact:
+            rec = self.results.view(torch.int64).view(-1, 2)
+            w0, w1 = rec[:, 0], rec[:, 1]
+            meta = (w1 >> 56) & 0xFF
+            m40 = (1 << 40) - 1
+            self.n_no_sa = int(((meta & 128) != 0).sum())
+            self.n_wide_rec = int(((meta & 64) != 0).sum())
+            uniq = (meta & 1) != 0
+            multi_m = (meta & 4) != 0
+            plain_res = torch.zeros((n_reads, 4), dtype=torch.int64, device=dev)
+            plain_res[:, 0] = w0 & m40
+            plain_res[:, 1] = (w0 & m40) + ((w0 >> 40) & 0xFFFFFF)
+            idx = torch.arange(n_reads, device=dev, dtype=torch.int64)
+            nh_t = torch.where(uniq, torch.ones_like(idx), torch.where(multi_m, (w1 >> 40) & 0xFFFF, torch.zeros_like(idx)))
+            plain_res[:, 2] = torch.where(uniq, idx, torch.where(multi_m & (nh_t > 0), n_reads + (w1 & m40), torch.zeros_like(idx)))
+            plain_res[:, 3] = nh_t | (((meta >> 3) & 3) << 32)
+            # unique hits at their read's index; the lists stay where they are (hits[]), addressed behind the first n_reads slots
+            plain_hits = torch.zeros((n_reads, 2), dtype=torch.int64, device=dev)
+            plain_hits[:, 0] = torch.where(uniq, w1 & m40, torch.zeros_like(idx))
+            plain_hits[:, 1] = torch.where(uniq, ((w1 >> 40) & 0xFFFF) | (((meta >> 1) & 1) << 32), torch.zeros_like(idx))
+            if self.layout == "hits":
+                # reads settled without an SA interval: the origin check expects a size-1 interval for a hit
+                no_sa = (meta & 128) != 0
+                plain_res[:, 1] = torch.where(no_sa & uniq, plain_res[:, 0] + 1, plain_res[:, 1])
+            del rec, w0, w1, idx, nh_t
+            self.results_plain = plain_res.view(-1).view(torch.uint8)
+            self.hits_plain = plain_hits.view(-1).view(torch.uint8)
+            self.list_hits = self.n_hits
+        else:
+            self.n_no_sa = self.n_wide_rec = 0
+            self.results_plain, self.hits_plain = self.results, self.hits.view(-1)[: n_reads * 16]
+            self.list_hits = self.n_hits - n_reads if self.n_hits >= n_reads else 0      # lists only, as in the compact layouts
+        self.res_np = np.frombuffer(self.results_plain.cpu().numpy().tobytes(), dtype=self.sb.api.RESULT_DTYPE)
+        self.mapped = int((self.res_np["nh"] > 0).sum())
+        self.multi = int((self.res_np["nh"] > 1).sum())
+
+    def parity(self, oracle_lib, probe_n, nthreads):
+        """the first probe_n reads through the oracle on the same tables: SA intervals (where the layout reports one), NH
+        and the ordered hit lists"""
+        torch, dev, n_reads = self.torch, self.dev, self.n_reads
+        oix = self.wl.oracle(oracle_lib)
+        if oix is None:
+            return None, None
+        probe_n = int(min(probe_n, n_reads))
+        hp = self.packed[:probe_n].cpu().numpy().view(np.uint32)
+        hl = self.lens[:probe_n].cpu().numpy().astype(np.uint32)
+        pseq, poff = unpack_reads(hp, hl)
+        t1 = time.perf_counter()
+        lo, hi, nh, first, ohits = oix.map_batch_raw(np.concatenate([pseq, np.zeros(1, np.uint8)]), poff, probe_n, nthreads=nthreads)
+        rate = probe_n / (time.perf_counter() - t1)
+        gres = self.res_np[:probe_n]
+        sa_ok = np.ones(probe_n, bool)
+        if self.layout == "hits":
+            sa_ok = ((self.results.view(torch.int64).view(-1, 2)[:probe_n, 1] >> 56) & 128).cpu().numpy() == 0
+        ok = bool(np.array_equal(gres["sa_lo"][sa_ok], lo[sa_ok]) and np.array_equal(gres["sa_hi"][sa_ok], hi[sa_ok])
+                  and np.array_equal(gres["nh"], nh))
+        if ok and int(nh.sum()):
+            # ordered hit lists of the probe reads, gathered on the device (the lists of multi-hit reads lie anywhere)
+            tot = int(nh.sum())
+            within = np.arange(tot) - np.repeat(np.cumsum(nh) - nh, nh)
+            gi = torch.from_numpy((np.repeat(gres["first_hit"], nh) + within).astype(np.int64)).to(dev)
+            # slots below n_reads: the unique hit of that read; above: the lists (hits[] itself in the compact layouts)
+            lists16 = self.hits.view(-1, 16)
+            list_base = 0 if self.compact else n_reads
+            in_list = gi >= n_reads
+            got = self.hits_plain.view(-1, 16)[torch.where(in_list, torch.zeros_like(gi), gi)]
+            got_l = lists16[torch.where(in_list, gi - n_reads + list_base, torch.zeros_like(gi))]
+            ghits = np.frombuffer(torch.where(in_list[:, None], got_l, got).cpu().numpy().tobytes(), dtype=self.sb.api.HIT_DTYPE)
+            oi = (np.repeat(first, nh) + within).astype(np.int64)
+            ok = bool(np.array_equal(ghits, ohits[oi]))
+        return {"reads_checked": probe_n, "identical": ok,
+                "compared": "NH and ordered hit lists of every read; SA intervals of the %d reads that report one" % int(sa_ok.sum())}, rate
+
+    def accounting(self):
+        """Algorithmic bytes of ONE launch of the dominant kernel: the search is a chain of random
+        accesses into index tables far larger than any cache, and HBM serves such an access as one 128-byte line whatever
+        part of it is used, so the unit is the line: 128 B x (index lines the reads of the batch need, counted by the
+        kernels themselves) + the streamed bytes (read record + length in, result + hit out)."""
+        n_reads, wpr, stats = self.n_reads, self.wpr, self.stats
+        km = self.kernel_ms
+        A = {"device_ms": float(np.mean([k[0] for k in km])), "search_ms": float(np.mean([k[1] for k in km])),
+             "multi_ms": float(np.mean([k[2] for k in km])), "settle_ms": float(np.mean([k[3] for k in km])),
+             "pending_ms": float(np.mean([k[4] for k in km]))}
+        out_bytes = 16 if self.compact else 48     # per read: one 16-byte record, or a 32-byte record + the 16-byte hit slot
+        if A["settle_ms"] > 0:
+            # the dominant kernel is the fast pass -- one bucket (one line) per looked-up read, records in, records out
+            A["kernel"], A["kernel_ms"] = ("k_settle" if (self.layout == "hits" and wpr == 4) else "k_direct"), A["settle_ms"]
+            A["accesses"] = int(stats[6])
+            A["streamed"] = n_reads * (wpr * 4 + 4 + out_bytes) + int(stats[7]) * 4
+        else:
+            A["kernel"], A["kernel_ms"] = "k_search_sm", A["search_ms"]
+            A["accesses"] = int(stats[0])
+            A["streamed"] = n_reads * (wpr * 4 + 4 + out_bytes) + int(self.list_hits) * 16
+        if A["multi_ms"] > A["kernel_ms"]:
+            # locate-bound workloads: the multi-hit kernels take most of the step; one text (or chain) line + the sa_full
+            # word in and a 16-byte hit out per raw row, the search kernel's lines on top
+            A["kernel"], A["kernel_ms"] = "multi-hit locate (k_multi_sort / k_multi_bfs)", A["multi_ms"]
+            A["accesses"] = int(self.list_hits)
+            A["streamed"] = int(self.list_hits) * (8 + 16)
+        A["out_bytes"] = out_bytes
+        A["algo_bytes"] = 128 * A["accesses"] + A["streamed"]
+        A["achieved_GBps"] = A["algo_bytes"] / (A["kernel_ms"] * 1e-3) / 1e9
+        A["all_accesses"] = int(stats[0])
+        return A
+
+    def summary(self, name, workload, parity, world=1):
+        """one short entry of the `configs` block"""
+        A = self.accounting()
+        st = self.stats
+        return {"name": name, "workload": workload, "layout": self.layout,
+                "reads_per_s": round(world * self.n_reads * self.steps / self.elapsed, 1),
+                "ms_per_step": round(self.elapsed / self.steps * 1e3, 3),
+                "kernel": A["kernel"], "kernel_ms": round(A["kernel_ms"], 3),
+                "index_lines_per_read": round(A["all_accesses"] / self.n_reads, 3),
+                "achieved_GBps": round(A["achieved_GBps"], 1), "frac": round(A["achieved_GBps"] / 8000.0, 4),
+                "hash_hit_rate": round(st[5] / st[4], 4) if st[4] else None,
+                "mapped_reads": self.mapped, "multi_hit_reads": self.multi, "list_hits": int(self.list_hits),
+                "multi_locate_ms": round(A["multi_ms"], 3), "reads_located_by_walk": int(st[3]),
+                "parity_vs_oracle": parity["identical"] if parity else None,
+                "reads_checked": parity["reads_checked"] if parity else 0}
+
+    def close(self):
+        if self.own_ctx and self.ctx is not None:
+            self.ctx.close()
+        self.ctx = None
+        self.results = self.hits = self.wide = None
+        self.results_plain = self.hits_plain = None
+        self.torch.cuda.empty_cache()
+
+
+def side_case(torch, dev, sb, oracle_lib, wl, name, workload, n_reads, L, layouts, steps, cores, min_len=None, seed=50,
+              probe_n=20000, packed=None, lens=None):
+    """a configuration beside the headline: its reads, a few steps per layout, the first probe_n reads against the oracle"""
+    wpr = sb.words_per_read(L)
+    if packed is None:
+        packed, lens = make_reads(torch, dev, wl.codes, wl.g, n_reads, L, seed=seed, wpr=wpr, min_len=min_len, slots=wl.slots)
+    torch.cuda.synchronize()     # the library's stream does not wait for torch's: the reads must be there before a step starts
+    out = []
+    ctx = sb.Context(wl.ix, n_reads)
+    try:
+        for layout in layouts:
+            run = Run(torch, dev, sb, wl, packed, lens, n_reads, L, wpr, layout, ctx=ctx)
+            try:
+                run.timed(steps, 1)
+                run.decode()
+                par, _ = run.parity(oracle_lib, probe_n, cores) if oracle_lib else (None, None)
+                out.append(run.summary(name, workload, par))
+            finally:
+                run.close()
+    finally:
+        ctx.close()
+    return out
+
+
+def file_path_case(torch, dev, sb, wl, cores, n_reads, L=50):
+    """Searcher_impl::load_table (searcher.hpp:190-204) at full size: the index the headline ran on, written in the
+    upstream file format (sbwt_host_tables_save + the three side files), loaded back (sbwt_index_load) and run on the
+    same reads -- the records must be the same bytes.  The built index is closed first: two replicas do not fit."""
+    wpr = sb.words_per_read(L)
+    packed, lens = make_reads(torch, dev, wl.codes, wl.g, n_reads, L, seed=77, wpr=wpr)
+    torch.cuda.synchronize()
+    results = torch.empty(n_reads * 16, dtype=torch.uint8, device=dev)
+    hits = torch.empty((1 << 20) * 16, dtype=torch.uint8, device=dev)
+    wide = torch.empty((1 << 16) * 48, dtype=torch.uint8, device=dev)
+
+    def once(ix):
+        ctx = sb.Context(ix, n_reads)
+        for _ in range(2):
+            ctx.map_batch_device_compact(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(), hits.data_ptr(),
+                                         1 << 20, wide.data_ptr(), 1 << 16, limit=1000, strand=2, mode=0)
+        ms = ctx.last_timing_ex()[0]
+        ctx.close()
+        return results.clone(), ms
+
+    ref, ms_built = once(wl.ix)
+    tmpd = tempfile.mkdtemp(prefix="sbwt_files_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        prefix = os.path.join(tmpd, "idx.")
+        t0 = time.time()
+        sb.host_tables_save(wl.tables, prefix + "t_table.bwt")
+        names = ["chr%d" % (k + 1) for k in range(len(wl.chr_start))]
+        with open(prefix + "chrStart", "w") as f:
+            for nm, v in zip(names, wl.chr_start):
+                f.write("%s\t%d\n" % (nm, v))
+        with open(prefix + "chrLen", "w") as f:
+            for nm, v in zip(names, wl.lens_chr):
+                f.write("%s\t%d\n" % (nm, v))
+        write_npos(prefix + "NposLen.z", wl.npos_key, wl.npos_val)
+        t_save = time.time() - t0
+        file_gb = os.path.getsize(prefix + "t_table.bwt") / 1e9
+        wl.ix.close()
+        wl.ix = None
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        ix2 = sb.Index.load(prefix, dev.index)
+        t_load = time.time() - t0
+        info2 = ix2.info()
+        got, ms_loaded = once(ix2)
+        # the same bytes -- except WHERE the list of a multi-hit read lies in hits[], which no call promises
+        ra, rb = ref.view(torch.int64).view(-1, 2), got.view(torch.int64).view(-1, 2)
+        multi = ((ra[:, 1] >> 56) & 4) != 0
+        same = bool(torch.equal(ra[:, 0], rb[:, 0]) and torch.equal(torch.where(multi, ra[:, 1] >> 40, ra[:, 1]),
+                                                                  torch.where(multi, rb[:, 1] >> 40, rb[:, 1])))
+        ix2.close()
+    finally:
+        shutil.rmtree(tmpd, ignore_errors=True)
+    return {"name": "index files", "workload": "the headline's index written in the upstream file format (%.2f GB t_table.bwt), "
+            "loaded with sbwt_index_load, %d x %d-bp reads" % (file_gb, n_reads, L), "layout": "compact",
+            "index_save_s": round(t_save, 1), "index_load_s": round(t_load, 1),
+            "reads_per_s": round(n_reads / (ms_loaded * 1e-3), 1), "device_ms_loaded": round(ms_loaded, 3),
+            "device_ms_built": round(ms_built, 3), "index_hbm_GB": round(info2.device_bytes / 1e9, 2),
+            "search_prefix_tables": {"direct_order": int(info2.kmer_order), "hash_order": int(info2.hash_order)},
+            "records_identical_to_built_index": same}
+
+
+def write_npos(path, keys, vals):
+    """prefix.NposLen.z in the upstream archive layout: header, map class-info, count, item version,
+    pair class-info, then (key, value) pairs"""
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", 22) + b"serialization::archive" + struct.pack("<H", 10) + bytes([4, 8, 4, 8]) + struct.pack("<I", 1))
+        f.write(b"\0" * 5 + struct.pack("<Q", len(keys)) + struct.pack("<I", 0) + b"\0" * 5)
+        for k, v in zip(keys, vals):
+            f.write(struct.pack("<QQ", int(k), int(v)))
+
+
+def strong_scaling(args, torch, dev, sb, dist, rank, world):
+    """BASELINE.json configs[3]: a fixed total of 800 M x 100-bp reads over 1/2/4/8 ranks.  sbwt_shard_range cuts the
+    input into contiguous shares (as Job_distributer::distribute_jobs, job_distributer.hpp:37-90, hands out groups of
+    ONE input in reading order); a rank holds its share in HBM and maps it chunk by chunk (compact records, hits only,
+    two result buffers in turn: what a consumer would drain while the next chunk maps)."""
+    from sbwt_amd import shard
+    L = args.read_len if args.read_len != 50 else 100
+    total = args.reads if args.reads != 100_000_000 else 800_000_000
+    wl = Workload(torch, dev, sb, scale=args.scale)
+    a, b = shard.shard_range(total, rank, world)
+    mine = b - a
+    wpr = sb.words_per_read(L)
+    chunk = int(min(args.chunk, max(mine, 1)))
+    free_b, _ = torch.cuda.mem_get_info()
+    need = mine * (wpr * 4 + 4) + 2 * chunk * 16 + (4 << 30)
+    if need > free_b:
+        raise SystemExit("bench.py --config 4: a share of %d reads (%.1f GB) does not fit the %.1f GB this GPU has left next to "
+                         "the index; use more ranks or --reads" % (mine, need / 1e9, free_b / 1e9))
+    t0 = time.time()
+    packed = torch.empty((mine, wpr), dtype=torch.int32, device=dev)
+    lens = torch.empty((mine,), dtype=torch.int32, device=dev)
+    gen = 1 << 24
+    for c in range(a // gen, (b - 1) // gen + 1 if mine else 0):
+        # piece c of the whole input (reads [c * gen, (c + 1) * gen)) is generated from seed 1000 + c whoever needs a
+        # part of it: read i of the input is the same read whatever the number of ranks
+        p, l = make_reads(torch, dev, wl.codes, wl.g, min(gen, total - c * gen), L, seed=1000 + c, wpr=wpr)
+        s0, s1 = max(a, c * gen), min(b, (c + 1) * gen)
+        packed[s0 - a:s1 - a] = p[s0 - c * gen:s1 - c * gen]
+        lens[s0 - a:s1 - a] = l[s0 - c * gen:s1 - c * gen]
+        del p, l
+    wl.drop_genome()
+    torch.cuda.synchronize()
+    t_reads = time.time() - t0
+    ctx = sb.Context(wl.ix, chunk)
+    outs = [torch.empty(chunk * 16, dtype=torch.uint8, device=dev) for _ in range(2)]
+    hits = torch.empty((1 << 20) * 16, dtype=torch.uint8, device=dev)
+    wide = torch.empty((1 << 16) * 48, dtype=torch.uint8, device=dev)
+    mapped = [0]
+    dev_ms = []
+
+    def step():
+        k = 0
+        ms = 0.0
+        for c0 in range(0, mine, chunk):
+            n = min(chunk, mine - c0)
+            ctx.map_batch_device_compact(packed[c0:].data_ptr(), lens[c0:].data_ptr(), n, wpr, outs[k & 1].data_ptr(), hits.data_ptr(),
+                                         1 << 20, wide.data_ptr(), 1 << 16, limit=1000, strand=2, mode=sb.MAP_HITS_ONLY)
+            ms += ctx.last_timing_ex()[0]
+            k += 1
+        dev_ms.append(ms)
+
+    elapsed = shard.timed_steps(step, args.steps, args.warmup, dist=dist, sync=torch.cuda.synchronize, device=dev)
+    # mapped reads of this rank's last chunk pass (a property check: error-free reads map unless they span a boundary)
+    n_last = mine - (mine - 1) // chunk * chunk if mine else 0
+    kk = ((mine - 1) // chunk) & 1 if mine else 0
+    if mine:
+        w1 = outs[kk].view(torch.int64).view(-1, 2)[:n_last, 1]
+        mapped[0] = int((((w1 >> 56) & 5) != 0).sum())
+    cnt = shard.sum_counters([mine, mapped[0], n_last], dist=dist)
+    if rank == 0:
+        line = {"metric": "mapped reads/sec (50bp exact, GRCh38) at 1/8 GPUs; achieved HBM GB/s",
+                "value": round(total * args.steps / elapsed, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": "BASELINE.json configs[3]: %s, a fixed total of %d x %d-bp exact reads cut into %d contiguous "
+                                       "shares (sbwt_shard_range), each resident in its GPU's HBM and mapped in chunks of %d reads, "
+                                       "both strands, -m 1000 -s 2, compact records, hits only" % (wl.describe(), total, L, world, chunk),
+                           "index_suffixes": int(wl.info.n), "index_hbm_GB": round(wl.info.device_bytes / 1e9, 2),
+                           "total_reads": total, "reads_this_rank": mine, "read_len": L, "chunk_reads": chunk,
+                           "parallelism": "replicated index, one input cut into %d contiguous shares" % world},
+                "roofline": None, "cpu_baseline": None,
+                "detail": {"reads_all_ranks": cnt[0], "device_ms_per_step_rank0": round(float(np.mean(dev_ms[-args.steps:])), 3),
+                           "mapped_in_last_chunks": cnt[1], "reads_in_last_chunks": cnt[2],
+                           "setup_s": {"genome": round(wl.t_genome, 1), "index_build": round(wl.t_index, 1), "reads": round(t_reads, 1)}}}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    wl.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +786,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end and configs[0] legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other configurations of the default run")
+    ap.add_argument("--force-configs", action="store_true", help="(debug) the configurations block at any --scale / --reads, sizes scaled along")
+    ap.add_argument("--only-configs", default="", help="(debug) comma-separated names: only these entries of the configurations block")
+    ap.add_argument("--configs-budget-s", type=float, default=330.0, help="no further configuration is started after this many seconds of run time")
     ap.add_argument("--min-len", type=int, default=None, help="reads of length min-len..read-len (config 5)")
     ap.add_argument("--mutate", type=float, default=0.0, help="fraction of reads with one substitution")
     ap.add_argument("--repeats", action="store_true", help="plant a repeat family, half of the reads inside it (config 5)")
@@ -355,17 +799,14 @@ def main():
     ap.add_argument("--layout", choices=["plain", "compact", "hits"], default="hits",
                     help="per-read output: plain = 32-byte record + hit slot per read (sbwt_map_batch_device); compact = 16-byte "
                          "records (sbwt_map_batch_device_compact); hits = compact with SBWT_MAP_HITS_ONLY (what SAM output needs)")
+    ap.add_argument("--config", type=int, default=0, help="4: BASELINE.json configs[3] as a strong-scaling run (fixed total of 8e8 x 100-bp reads)")
+    ap.add_argument("--chunk", type=int, default=50_000_000, help="--config 4: reads per resident chunk")
     args = ap.parse_args()
+    t_start = time.time()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus, sys.argv[1:])
         return
-
-    if args.rank_path:
-        os.environ["SBWT_HASH_ORDER"] = "0"
-        os.environ["SBWT_KMER_ORDER"] = "12"
-    if args.shuffle_ties:
-        os.environ["SBWT_DEBUG_SORT_DEPTH"] = "256"
 
     import torch
     import sbwt_amd
@@ -387,80 +828,45 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    t0 = time.time()
-    L = args.read_len
-    lens_chr, g, chr_start, npos_key, npos_val = synth_tables(args.scale)
-    codes, packed_genome = make_genome(torch, dev, g, seed=38)
-    slots = None
-    repeat_cover = None
-    if args.genome == "repeats":
-        repeat_cover = plant_repeat_families(torch, dev, codes, g, seed=40)
-        packed_genome = repack(torch, dev, codes, g)
-    if args.repeats:
-        slots = plant_repeats(torch, dev, codes, g, seed=5)
-        packed_genome = repack(torch, dev, codes, g)
-    torch.cuda.synchronize()
-    t_genome = time.time() - t0
+    if args.config == 4:
+        strong_scaling(args, torch, dev, sbwt_amd, dist, rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.config:
+        raise SystemExit("bench.py: --config takes 4 (the other configurations are part of the default run)")
 
+    L = args.read_len
     # index: suffix order + tables on the GPU, straight into the HBM layout; rank 0 of a single-GPU run also exports
     # the reference-format tables for the CPU baseline leg and the oracle spot check
     run_cpu = (world == 1 and not args.no_cpu)
-    want_tables = run_cpu
-    t0 = time.time()
-    ix, tables = sbwt_amd.build_index_device(packed_genome.data_ptr(), g, chr_start, npos_key, npos_val, interval=64,
-                                             device=local, want_index=True, want_tables=want_tables)
-    t_index = time.time() - t0
-    del packed_genome
-    info = ix.info()
+    wl = Workload(torch, dev, sbwt_amd, scale=args.scale, genome=args.genome, plant=args.repeats, rank_path=args.rank_path,
+                  shuffle_ties=args.shuffle_ties, want_tables=run_cpu)
+    ix, info = wl.ix, wl.info
+    g, chr_start, npos_key, npos_val = wl.g, wl.chr_start, wl.npos_key, wl.npos_val
+    default_workload = (args.min_len is None and not args.repeats and args.mutate == 0.0 and args.genome == "iid"
+                        and not args.rank_path and not args.shuffle_ties)
 
     wpr = sbwt_amd.words_per_read(L)
     n_reads = args.reads
     t0 = time.time()
-    plain = args.min_len is None and slots is None and args.mutate == 0.0 and args.genome == "iid"
+    plain = args.min_len is None and wl.slots is None and args.mutate == 0.0 and args.genome == "iid"
     origins = [] if (plain and rank == 0) else None
-    packed, lens = make_reads(torch, dev, codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=slots,
+    packed, lens = make_reads(torch, dev, wl.codes, g, n_reads, L, seed=50 + rank, wpr=wpr, min_len=args.min_len, slots=wl.slots,
                               mutate=args.mutate, origins=origins)
-    del codes
-    torch.cuda.empty_cache()
+    do_configs = (world == 1 and default_workload and not args.no_configs and L == 50 and args.layout == "hits"
+                  and ((args.scale == 1.0 and n_reads == 100_000_000) or args.force_configs))
+    if not do_configs:
+        wl.drop_genome()
     torch.cuda.synchronize()
     t_reads = time.time() - t0
 
-    many_hits = args.repeats or args.genome == "repeats"
-    ctx = sbwt_amd.Context(ix, n_reads)
-    compact = args.layout != "plain"
-    mode = sbwt_amd.MAP_HITS_ONLY if args.layout == "hits" else 0
-    wide_cap = 1 << 16
-    free_b, _ = torch.cuda.mem_get_info()
-    list_cap = int(min(80 * n_reads, max(1 << 20, (free_b - (6 << 30)) // 16)))       # room for the lists of multi-hit reads
-    if compact:
-        results = torch.empty(n_reads * 16, dtype=torch.uint8, device=dev)            # sbwt_compact_result[n_reads]
-        hits_cap = (1 << 20) if not many_hits else list_cap                           # lists of multi-hit reads only
-        wide = torch.empty(wide_cap * 48, dtype=torch.uint8, device=dev)
-    else:
-        results = torch.empty(n_reads * 32, dtype=torch.uint8, device=dev)            # sbwt_read_result[n_reads]
-        hits_cap = n_reads + (1 << 20) if not many_hits else n_reads + list_cap
-    hits = torch.empty(hits_cap * 16, dtype=torch.uint8, device=dev)
-
-    def step():
-        if compact:
-            return ctx.map_batch_device_compact(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
-                                                hits.data_ptr(), hits_cap, wide.data_ptr(), wide_cap, limit=1000, strand=2,
-                                                mode=mode)
-        return (ctx.map_batch_device(packed.data_ptr(), lens.data_ptr(), n_reads, wpr, results.data_ptr(),
-                                     hits.data_ptr(), hits_cap, limit=1000, strand=2), 0)
-
-    from sbwt_amd import shard
-    kernel_ms = []
-    last = {"hits": (0, 0)}
-
-    def timed_step():
-        last["hits"] = step()                   # synchronises its own stream before returning
-        kernel_ms.append(ctx.last_timing_ex())  # HIP events on the ctx stream, around the kernels of this step
-
-    for _ in range(args.warmup):
-        step()
-    elapsed = shard.timed_steps(timed_step, args.steps, 0, dist=dist, sync=torch.cuda.synchronize, device=dev)
-    n_hits, n_wide = last["hits"]
+    many_hits = wl.many_hits
+    head = Run(torch, dev, sbwt_amd, wl, packed, lens, n_reads, L, wpr, args.layout)
+    compact = head.compact
+    elapsed = head.timed(args.steps, args.warmup, dist=dist)
+    n_hits, n_wide = head.n_hits, head.n_wide
 
     if rank != 0:
         if dist is not None:
@@ -468,73 +874,19 @@ def main():
             dist.destroy_process_group()
         return
 
-    if compact:
-        # decode the compact records on the device into the plain layout (only for the checks below, after the timed region)
-        rec = results.view(torch.int64).view(-1, 2)
-        w0, w1 = rec[:, 0], rec[:, 1]
-        meta = (w1 >> 56) & 0xFF
-        m40 = (1 << 40) - 1
-        n_no_sa = int(((meta & 128) != 0).sum())
-        n_wide_rec = int(((meta & 64) != 0).sum())
-        uniq = (meta & 1) != 0
-        multi_m = (meta & 4) != 0
-        plain_res = torch.zeros((n_reads, 4), dtype=torch.int64, device=dev)
-        plain_res[:, 0] = w0 & m40
-        plain_res[:, 1] = (w0 & m40) + ((w0 >> 40) & 0xFFFFFF)
-        idx = torch.arange(n_reads, device=dev, dtype=torch.int64)
-        nh_t = torch.where(uniq, torch.ones_like(idx), torch.where(multi_m, (w1 >> 40) & 0xFFFF, torch.zeros_like(idx)))
-        plain_res[:, 2] = torch.where(uniq, idx, torch.where(multi_m & (nh_t > 0), n_reads + (w1 & m40), torch.zeros_like(idx)))
-        plain_res[:, 3] = nh_t | (((meta >> 3) & 3) << 32)
-        # unique hits at their read's index; the lists stay where they are (hits[]), addressed behind the first n_reads slots
-        plain_hits = torch.zeros((n_reads, 2), dtype=torch.int64, device=dev)
-        plain_hits[:, 0] = torch.where(uniq, w1 & m40, torch.zeros_like(idx))
-        plain_hits[:, 1] = torch.where(uniq, ((w1 >> 40) & 0xFFFF) | (((meta >> 1) & 1) << 32), torch.zeros_like(idx))
-        del rec, w0, w1, idx, nh_t
-        if args.layout == "hits":
-            # reads settled without an SA interval: the origin check below expects a size-1 interval for a hit
-            no_sa = (meta & 128) != 0
-            plain_res[:, 1] = torch.where(no_sa & uniq, plain_res[:, 0] + 1, plain_res[:, 1])
-        results_plain = plain_res.view(-1).view(torch.uint8)
-        hits_plain = plain_hits.view(-1).view(torch.uint8)
-    else:
-        n_no_sa = n_wide_rec = 0
-        results_plain, hits_plain = results, hits.view(-1)[: n_reads * 16]
-        n_hits = n_hits - n_reads if n_hits >= n_reads else 0      # lists only, as in the compact layouts
+    head.decode()
+    n_hits = head.list_hits
     origin = None
     if origins is not None:
-        origin = origin_check(torch, dev, results_plain, hits_plain, origins, L, chr_start, npos_key, npos_val)
+        origin = origin_check(torch, dev, head.results_plain, head.hits_plain, origins, L, chr_start, npos_key, npos_val)
         del origins
     value = world * n_reads * args.steps / elapsed
-    search_ms = float(np.mean([k[1] for k in kernel_ms]))
-    multi_ms = float(np.mean([k[2] for k in kernel_ms]))
-    res_np = np.frombuffer(results_plain.cpu().numpy().tobytes(), dtype=sbwt_amd.api.RESULT_DTYPE)
-    mapped = int((res_np["nh"] > 0).sum())
-    multi = int((res_np["nh"] > 1).sum())
-    no_sa_np = None
-    if args.layout == "hits":
-        no_sa_np = ((results.view(torch.int64).view(-1, 2)[:20000, 1] >> 56) & 128).cpu().numpy() != 0
-    # Algorithmic bytes of ONE k_search_sm launch: the search is a chain of random accesses
-    # into index tables far larger than any cache, and HBM serves such an access as one 128-byte line whatever
-    # part of it is used, so the unit is the line: 128 B x (index lines the reads of the batch need, counted by
-    # the kernel itself: search-prefix entry, two-base blocks, memoised locate, text comparison, final row)
-    # + the streamed bytes (read record + length in, result + hit out).
-    stats = ctx.last_stats_ex()
-    settle_ms = float(np.mean([k[3] for k in kernel_ms]))
-    pending_ms = float(np.mean([k[4] for k in kernel_ms]))
-    out_bytes = 16 if compact else 48     # per read: one 16-byte record, or a 32-byte record + the 16-byte hit slot
-    if settle_ms > 0:
-        # hits layout: the dominant kernel is k_settle -- one bucket (one line) per looked-up read, records in, records out
-        dom_kernel, dom_ms = ("k_settle" if (args.layout == "hits" and wpr == 4) else "k_direct"), settle_ms
-        accesses = int(stats[6])
-        streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(stats[7]) * 4
-    else:
-        dom_kernel, dom_ms = "k_search_sm", search_ms
-        accesses = int(stats[0])
-        streamed = n_reads * (wpr * 4 + 4 + out_bytes) + int(n_hits) * 16
-    algo_bytes = 128 * accesses + streamed
-    requests = accesses + (streamed - n_reads * out_bytes) / 128.0 + n_reads * out_bytes / 64.0   # (PMC of the same kernel: within 1 %)
-    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-    all_accesses = int(stats[0])
+    A = head.accounting()
+    stats = head.stats
+    dom_kernel, dom_ms, accesses, algo_bytes = A["kernel"], A["kernel_ms"], A["accesses"], A["algo_bytes"]
+    out_bytes = A["out_bytes"]
+    requests = accesses + (A["streamed"] - n_reads * out_bytes) / 128.0 + n_reads * out_bytes / 64.0   # (PMC of the same kernel: within 1 %)
+    achieved = A["achieved_GBps"]
     survey_per_read = 16 + 64 * (2 * (L - 12) + 32.5)   # reference-layout bytes per unique read
     # the random-access roofline of THIS device, measured in this process over the index's own largest table
     probe = {}
@@ -554,40 +906,36 @@ def main():
         sys.stderr.write("stream gather probe skipped: %s\n" % e)
     lines_per_s = accesses / (dom_ms * 1e-3) / 1e9
     stored = None
-    tpath = os.path.join(ROOT, "profiles", "r2", "traffic_%s.json" % args.layout)   # PMC passes of an earlier run: context only
-    if os.path.exists(tpath):
-        t = json.load(open(tpath))
-        if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9 and plain \
-                and not args.rank_path and t.get("kernel") == dom_kernel:
-            stored = {"source": "profiles/r2/traffic_%s.json (rocprofv3 --pmc passes of the same command on another box of this "
-                                "pool; NOT measured in this run)" % args.layout,
-                      "traffic_GB_per_launch": t.get("traffic_GB_per_launch"),
-                      "hbm_requests_per_launch": t.get("hbm_requests_per_launch")}
+    for tdir in ("r3", "r2"):                      # PMC passes of an earlier run of the same command: context only
+        tpath = os.path.join(ROOT, "profiles", tdir, "traffic_%s.json" % args.layout)
+        if stored is None and os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9 and plain \
+                    and not args.rank_path and t.get("kernel") == dom_kernel:
+                stored = {"source": "profiles/%s/traffic_%s.json (rocprofv3 --pmc passes of the same command on another box of this "
+                                    "pool; NOT measured in this run)" % (tdir, args.layout),
+                          "traffic_GB_per_launch": t.get("traffic_GB_per_launch"),
+                          "hbm_requests_per_launch": t.get("hbm_requests_per_launch")}
     roofline = {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": stored["traffic_GB_per_launch"] if stored else None,
                 "traffic_source": stored["source"] if stored else None,
                 "launch_ms": round(dom_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
-                "algorithmic_bytes": "128 B per index line the kernel reads (a random access moves one 128-byte line of HBM whatever "
-                                     "part of it is used: the probe below runs at the same rate for 16 .. 128-byte granules) + streamed "
-                                     "bytes (record and length in, result out)",
+                "algorithmic_bytes": "128 B per index line the kernel reads + streamed bytes (record and length in, result out); DESIGN.md section 3",
                 "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
                 "index_lines_per_s_G": round(lines_per_s, 2),
                 "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
                                     "table_GB": round(pbytes / 1e9, 1), "by_chains_per_lane": probe, "peak": gather_peak,
                                     "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3),
+                                    # independent random lines whose addresses come from a streamed 16-byte record, a 16-byte
+                                    # result written per line (k_probe_stream): the ceiling of a one-line-per-read kernel
                                     "streamed_gather_G_lines_per_s": round(stream_gather, 2) if stream_gather else None,
-                                    "streamed_gather": "independent random lines whose addresses come from a streamed 16-byte record, "
-                                                       "a 16-byte result written per line, nothing else (k_probe_stream): the "
-                                                       "ceiling of a one-line-per-read mapping kernel on this device",
                                     "kernel_frac_of_streamed_gather": round(lines_per_s / stream_gather, 3) if stream_gather else None,
-                                    # the probe issues nothing but random reads; the kernel also streams its records in and
-                                    # out, and those requests share the same memory pipeline: index lines + 128-byte read
-                                    # requests of the streamed input + 64-byte write requests of the output
+                                    # index lines + 128-byte read requests of the streamed input + 64-byte write requests of the output
                                     "kernel_hbm_requests_per_s_G": round(requests / (dom_ms * 1e-3) / 1e9, 2),
                                     "kernel_hbm_requests_frac": round(requests / (dom_ms * 1e-3) / 1e9 / gather_peak, 3)},
-                "whole_step": {"device_ms": round(float(np.mean([k[0] for k in kernel_ms])), 3),
-                               "index_lines_per_read": round(all_accesses / n_reads, 3),
-                               "fast_pass_ms": round(settle_ms, 3), "pending_pass_ms": round(pending_ms, 3),
+                "whole_step": {"device_ms": round(A["device_ms"], 3),
+                               "index_lines_per_read": round(A["all_accesses"] / n_reads, 3),
+                               "fast_pass_ms": round(A["settle_ms"], 3), "pending_pass_ms": round(A["pending_ms"], 3),
                                "reads_left_pending": int(stats[7])},
                 "hash_lookups_per_read": round(stats[4] / n_reads, 4), "hash_hit_rate": round(stats[5] / stats[4], 4) if stats[4] else None,
                 "stored_pmc": stored,
@@ -597,53 +945,28 @@ def main():
     parity = None
     end_to_end = None
     config1 = None
+    oracle_lib = None
     cores = min(16, os.cpu_count() or 1)
     if run_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
-        oix = oracle_index_from_tables(oracle_lib, tables, chr_start, npos_key, npos_val)
-        probe_n = int(min(20000, n_reads))
+        oix = wl.oracle(oracle_lib)
+        parity, rate1 = head.parity(oracle_lib, 20000, 1)
+        probe_n = parity["reads_checked"]
         sample_max = 8_000_000
         host_packed = packed[:sample_max].cpu().numpy().view(np.uint32)
         host_lens = lens[:sample_max].cpu().numpy().astype(np.uint32)
-        pseq, poff = unpack_reads(host_packed[:probe_n], host_lens[:probe_n])
-        t1 = time.perf_counter()
-        lo, hi, nh, first, ohits = oix.map_batch_raw(np.concatenate([pseq, np.zeros(1, np.uint8)]), poff, probe_n, nthreads=1)
-        rate1 = probe_n / (time.perf_counter() - t1)
-        # parity of the same reads through the GPU path
-        gres = res_np[:probe_n]
-        sa_ok = np.ones(probe_n, bool) if no_sa_np is None else ~no_sa_np[:probe_n]
-        ok = bool(np.array_equal(gres["sa_lo"][sa_ok], lo[sa_ok]) and np.array_equal(gres["sa_hi"][sa_ok], hi[sa_ok])
-                  and np.array_equal(gres["nh"], nh))
-        if ok and int(nh.sum()):
-            # ordered hit lists of the probe reads, gathered on the device (the lists of multi-hit reads lie anywhere)
-            tot = int(nh.sum())
-            within = np.arange(tot) - np.repeat(np.cumsum(nh) - nh, nh)
-            gi = torch.from_numpy((np.repeat(gres["first_hit"], nh) + within).astype(np.int64)).to(dev)
-            # slots below n_reads: the unique hit of that read; above: the lists (hits[] itself in the compact layouts)
-            lists16 = hits.view(-1, 16)
-            list_base = 0 if compact else n_reads
-            in_list = gi >= n_reads
-            got = hits_plain.view(-1, 16)[torch.where(in_list, torch.zeros_like(gi), gi)]
-            got_l = lists16[torch.where(in_list, gi - n_reads + list_base, torch.zeros_like(gi))]
-            ghits = np.frombuffer(torch.where(in_list[:, None], got_l, got).cpu().numpy().tobytes(), dtype=sbwt_amd.api.HIT_DTYPE)
-            oi = (np.repeat(first, nh) + within).astype(np.int64)
-            ok = bool(np.array_equal(ghits, ohits[oi]))
-        parity = {"reads_checked": probe_n, "identical": ok,
-                  "compared": "NH and ordered hit lists of every read; SA intervals of the %d reads that report one" % int(sa_ok.sum())}
         sample_n = int(min(sample_max, host_lens.size, max(probe_n, rate1 * cores * args.cpu_seconds * 0.7)))
         seqs, offsets = unpack_reads(host_packed[:sample_n], host_lens[:sample_n])
         t1 = time.perf_counter()
         oix.map_batch_raw(np.concatenate([seqs, np.zeros(1, np.uint8)]), offsets, sample_n, nthreads=cores)
         dt = time.perf_counter() - t1
+        del seqs, offsets
         cpu = {"value": round(sample_n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
                "host_cpus": os.cpu_count(),
                "sample": "first %d reads of the same batch, same index (reference-format tables), %d threads; "
                          "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n),
-               "note": "the port is about 2x the reference binary per thread (7.9e4 vs 3.4-4.1e4 reads/s on configs[0] in the "
-                       "survey container, SURVEY.md section 6): it is a baseline beside the kernel, not the target"}
-        oix.close()
-        sbwt_amd.host_tables_free(tables)
+               "note": "the port is about 2x the reference binary per thread (SURVEY.md section 6): a baseline beside the kernel, not the target"}
         if not args.no_extras and args.min_len is None:
             # end to end, measured in this run (never `value`): (a) host buffers in, host buffers out through
             # page-locked memory (PCIe both ways), (b) FASTQ file -> SAM file with 16 host threads
@@ -696,12 +1019,8 @@ def main():
                           "host_buffers_plain_layout_reads_per_s": round(n_e / best, 1) if best else None,
                           "fastq_to_sam_reads_per_s": round(n_f / fbest, 1), "fastq_to_sam_reads": n_f, "host_threads": cores,
                           "fastq_MB": round(fq_bytes / 1e6), "sam_MB": round(sam_bytes / 1e6), "sam_records": int(st[4])}
-        if not args.no_extras and plain and args.scale == 1.0:
-            config1 = cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores)
 
-    workload_genome = "GRCh38-sized synthetic genome (%.3f Gbp non-N, 24 contigs, N runs%s%s)" % (
-        g / 1e9, ", planted repeat family" if args.repeats else "",
-        ", %.0f %% of the bases in diverged repeat families + exact duplications" % (100 * repeat_cover) if repeat_cover else "")
+    workload_genome = wl.describe()
     line = {
         "metric": "mapped reads/sec (50bp exact, GRCh38) at 1/8 GPUs; achieved HBM GB/s",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -719,16 +1038,93 @@ def main():
                                      "hits": "16-byte record per read, SBWT_MAP_HITS_ONLY: hits, NH and flags of every read; no SA interval "
                                              "for reads their located prefix settles (what the SAM output needs)"}[args.layout],
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
-        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": config1,
-        "detail": {"mapped_reads": mapped, "multi_hit_reads": multi, "list_hits": int(n_hits), "wide_records": n_wide_rec,
-                   "reads_without_sa_interval": n_no_sa, "reads_to_multi_hit_locate": int(stats[1]),
-                   "reads_sharing_a_located_list": int(stats[8]) if len(stats) > 8 else 0, "reads_to_depth_first_locate": int(stats[3]), "of_which_level_by_level": int(stats[9]) if len(stats) > 9 else 0, "reads_settled_by_a_miss": int(stats[10]) if len(stats) > 10 else 0,
-                   "k_search_ms": round(search_ms, 3), "k_multi_ms": round(multi_ms, 3),
-                   "fast_pass_ms": round(float(np.mean([k[3] for k in kernel_ms])), 3),
-                   "pending_pass_ms": round(float(np.mean([k[4] for k in kernel_ms])), 3),
-                   "setup_s": {"genome": round(t_genome, 1), "index_build": round(t_index, 1), "reads": round(t_reads, 1)},
+        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": None,
+        "detail": {"mapped_reads": head.mapped, "multi_hit_reads": head.multi, "list_hits": int(n_hits), "wide_records": head.n_wide_rec,
+                   "reads_without_sa_interval": head.n_no_sa, "reads_to_multi_hit_locate": int(stats[1]),
+                   "reads_sharing_a_located_list": int(stats[8]), "reads_to_depth_first_locate": int(stats[3]),
+                   "of_which_level_by_level": int(stats[9]), "reads_settled_by_a_miss": int(stats[10]),
+                   "k_search_ms": round(A["search_ms"], 3), "k_multi_ms": round(A["multi_ms"], 3),
+                   "fast_pass_ms": round(A["settle_ms"], 3), "pending_pass_ms": round(A["pending_ms"], 3),
+                   "setup_s": {"genome": round(wl.t_genome, 1), "index_build": round(wl.t_index, 1), "reads": round(t_reads, 1)},
                    "parity_vs_oracle": parity, "origin_check": origin},
     }
+    head.close()
+
+    # ---- the other configurations (after the headline's timed region; each checked against the oracle) ----------
+    if do_configs:
+        configs = []
+        skipped = []
+        olib = oracle_lib if run_cpu else None
+
+        only = [x for x in args.only_configs.split(",") if x]
+
+        def guarded(name, fn):
+            if only and name not in only:
+                return
+            if time.time() - t_start > args.configs_budget_s:
+                skipped.append(name)
+                return
+            t1 = time.time()
+            try:
+                out = fn()
+                for e in (out if isinstance(out, list) else [out]):
+                    e["took_s"] = round(time.time() - t1, 1)
+                    configs.append(e)
+            except Exception as e:   # a side line must never cost the headline
+                configs.append({"name": name, "error": "%s: %s" % (type(e).__name__, e)})
+                torch.cuda.empty_cache()
+
+        steps_side = 3
+        w3 = "configs[2] (the headline's index and reads), SA intervals reported"
+        guarded("config3_intervals", lambda: side_case(torch, dev, sbwt_amd, olib, wl, "config3_intervals", w3, n_reads, L,
+                                                       ["compact", "plain"], steps_side, cores, packed=packed, lens=lens))
+        del packed, lens
+        torch.cuda.empty_cache()
+        guarded("config4_per_gpu", lambda: side_case(torch, dev, sbwt_amd, olib, wl, "config4_per_gpu",
+                                                     "configs[3] per GPU: the same index, %d x 100-bp reads" % n_reads, n_reads, 100,
+                                                     ["hits", "compact"], steps_side, cores, seed=51))
+        if run_cpu and not args.no_extras:
+            guarded("index_files", lambda: file_path_case(torch, dev, sbwt_amd, wl, cores, n_reads // 10))
+        wl.close()
+
+        def fresh(name, workload, n, rl, layouts, probe_n=20000, min_len=None, **kw):
+            def fn():
+                kw.setdefault("scale", args.scale)
+                w2 = Workload(torch, dev, sbwt_amd, want_tables=run_cpu, **kw)
+                try:
+                    out = side_case(torch, dev, sbwt_amd, olib, w2, name, workload % w2.describe(), n, rl, layouts, steps_side, cores,
+                                    min_len=min_len, probe_n=probe_n)
+                    for e in out:
+                        e["index_suffixes"] = int(w2.info.n)
+                        e["index_build_s"] = round(w2.t_index, 1)
+                    return out
+                finally:
+                    w2.close()
+            guarded(name, fn)
+
+        n_mid, n_small = n_reads // 5, n_reads // 10     # 2 x 10^7 and 10^7 in the full-size run
+        fresh("config2_dm6", "configs[1]: %%s, %d x 36-bp reads" % n_small, n_small, 36, ["hits", "compact"], scale=0.0486 * args.scale)
+        fresh("repeats", "%%s, %d x 50-bp reads" % n_mid, n_mid, 50, ["hits"], probe_n=5000, genome="repeats")
+        fresh("repeats_shuffled_ties", "%%s, suffix order stopped at sort_len 256 with ties shuffled (what upstream's builder "
+              "leaves), %d x 50-bp reads" % n_mid, n_mid, 50, ["hits"], probe_n=5000, genome="repeats", shuffle_ties=True)
+        fresh("config5_smallrna", "configs[4] per GPU: %%s, %d x 18..30-nt reads, half of them inside the family" % n_mid, n_mid, 30,
+              ["hits"], probe_n=5000, min_len=18, plant=True)
+        fresh("rank_path", "%%s, %d x 50-bp reads, no memoised search prefix (12-mer table + rank queries)" % n_reads, n_reads, 50,
+              ["compact"], rank_path=True)
+        if run_cpu and not args.no_extras:
+            try:
+                line["cpu_baseline_config1"] = cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores)
+            except Exception as e:
+                line["cpu_baseline_config1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["configs"] = configs
+        if skipped:
+            line["configs_skipped_for_time"] = skipped
+        line["run_s"] = round(time.time() - t_start, 1)
+    else:
+        if run_cpu and not args.no_extras and plain and args.scale == 1.0:
+            wl.close()
+            line["cpu_baseline_config1"] = cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores)
+        wl.close()
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -474,8 +474,9 @@ __global__ __launch_bounds__(256) void k_planes2(DeviceIndex ix, Block2* __restr
     Block2* o = blocks2 + b;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o->plane[k] = planes[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o->reserved[k] = 0;
+    o->chain_rows = 0;
+    o->chain_base = 0;
+    o->reserved[0] = o->reserved[1] = 0;
   }
 }
 
@@ -507,6 +508,108 @@ __global__ __launch_bounds__(256) void k_apply2(Block2* __restrict__ blocks, uin
     const uint64_t base = chunk_base[(uint64_t)blockIdx.x * 16 + k], sbase = chunk_base[sb_chunk * 16 + k];
     if (live) blocks[b].cnt[k] = (uint32_t)(base - sbase + ex);
     if (blockIdx.x == sb_chunk && threadIdx.x == 0) sb_abs[sb * 16 + k] = k2[k] + sbase;
+  }
+}
+
+// ---- chain_tab: the depth-first locate of one row, memoised (device_layout.h) ---------------------------------
+// Which rows need an entry: those whose locate sa_full and the text do not answer for -- no position, or a run too
+// short for the text to stand in for the chain over the whole depth of the walk (the test k_multi_sort applies).
+__device__ __forceinline__ bool chain_row_needed(const DeviceIndex& ix, uint64_t e) {
+  if (e == kNoPosition) return true;
+  const uint64_t p = e & kPosMask;
+  return (e >> kPosBits) < (p + 1 < ix.interval ? p + 1 : ix.interval);
+}
+
+// one wave per index block, lane j owns row 64b + j
+__global__ __launch_bounds__(256) void k_chain_rows(DeviceIndex ix, Block2* __restrict__ blocks2) {
+  const uint64_t gid = global_thread();
+  const uint64_t b = gid >> 6;
+  if (b >= ix.n_blocks) return;  // wave-uniform
+  const uint64_t i = gid;
+  const bool need = i < ix.n && chain_row_needed(ix, ix.sa_full[i]);
+  const uint64_t bits = __ballot(need);
+  if ((threadIdx.x & 63) == 0) blocks2[b].chain_rows = bits;
+}
+// totals[chunk] = rows with an entry in one chunk of 256 blocks; then (after k_scan_chunks) chain_base of every block
+__global__ __launch_bounds__(256) void k_chain_totals(const Block2* __restrict__ blocks2, uint64_t n_blocks, uint64_t* __restrict__ totals) {
+  __shared__ uint32_t lds[4];
+  const uint64_t b = (uint64_t)blockIdx.x * kChunk + threadIdx.x;
+  uint32_t tot;
+  block_excl_scan(b < n_blocks ? (uint32_t)__popcll(blocks2[b].chain_rows) : 0u, lds, &tot);
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_chain_bases(Block2* __restrict__ blocks2, uint64_t n_blocks, const uint64_t* __restrict__ chunk_base) {
+  __shared__ uint32_t lds[4];
+  const uint64_t b = (uint64_t)blockIdx.x * kChunk + threadIdx.x;
+  uint32_t tot;
+  const uint32_t ex = block_excl_scan(b < n_blocks ? (uint32_t)__popcll(blocks2[b].chain_rows) : 0u, lds, &tot);
+  if (b < n_blocks) blocks2[b].chain_base = chunk_base[blockIdx.x] + ex;
+}
+__global__ __launch_bounds__(256) void k_chain_clear(Block2* __restrict__ blocks2, uint64_t n_blocks) {
+  const uint64_t b = global_thread();
+  if (b < n_blocks) { blocks2[b].chain_rows = 0; blocks2[b].chain_base = 0; }
+}
+
+// The chain of row i (device_layout.h): up to interval - 1 LF steps, every sampled row on the way an event.  kWrite
+// false: only counts the events beyond the first (total_extra); true: writes the entry and its further events (slots
+// handed out through next_extra).  One wave per index block, lane j owns row 64b + j.
+template <bool kWrite>
+__global__ __launch_bounds__(256) void k_chain_walk(DeviceIndex ix, ChainEntry* __restrict__ tab, uint64_t* __restrict__ ev,
+                                                    unsigned long long* __restrict__ extra_counter) {
+  const uint64_t gid = global_thread();
+  const uint64_t b = gid >> 6;
+  if (b >= ix.n_blocks) return;  // wave-uniform
+  const uint32_t lane = threadIdx.x & 63;
+  const Block2* blk2 = ix.blocks2 + b;
+  const uint64_t rows = blk2->chain_rows;
+  if (!rows) return;  // wave-uniform
+  const bool mine = (rows >> lane) & 1ull;
+  uint64_t k0 = 0, k1 = 0, ev0 = 0, first_extra = 0;
+  uint32_t n_ev = 0, len = 0;
+  for (int pass = 0; pass < (kWrite ? 2 : 1); ++pass) {
+    // (writing: the first pass counts the chain's events so that its slots in chain_ev can be taken in one piece)
+    if (kWrite && pass == 1) {
+      if (mine && n_ev > 1) first_extra = atomicAdd(extra_counter, (unsigned long long)(n_ev - 1));
+      n_ev = 0;
+    }
+    if (mine) {
+      uint64_t cur = gid;
+      for (uint64_t d = 0; d < ix.interval; ++d) {
+        const Block1* bl = ix.blocks1 + (cur >> 6);
+        const uint32_t o = (uint32_t)(cur & 63);
+        const uint64_t sampled = bl->sampled;
+        if ((sampled >> o) & 1ull) {
+          const uint64_t e = (d << 58) | ((ix.loc_vals[bl->sampled_base + (uint64_t)__popcll(sampled & below(o))] + d) & kPosMask);
+          if (n_ev == 0) ev0 = e;
+          else if (kWrite && pass == 1) ev[first_extra + n_ev - 1] = e;
+          ++n_ev;
+        }
+        if (d + 1 >= ix.interval || cur == ix.first_location) break;  // find_possible: len >= interval; the '$' row has no children
+        const uint64_t plo = bl->plane_lo, phi = bl->plane_hi;
+        const uint32_t c = (uint32_t)((plo >> o) & 1ull) | ((uint32_t)((phi >> o) & 1ull) << 1);
+        if (pass == 0) {
+          if (d < 32) k0 |= (uint64_t)c << (62 - 2 * d); else k1 |= (uint64_t)c << (62 - 2 * (d - 32));
+          len = (uint32_t)d + 1;
+        }
+        uint64_t r = bl->cnt[c] + (uint64_t)__popcll(match1(plo, phi, c) & below(o));
+        if (c == 0 && cur > ix.first_location) r -= 1;
+        cur = r;
+      }
+    }
+  }
+  if (!kWrite) {
+    unsigned long long extra = mine && n_ev > 1 ? n_ev - 1 : 0;
+    for (int d = 32; d > 0; d >>= 1) extra += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)extra, d));
+    if (lane == 0 && extra) atomicAdd(extra_counter, extra);
+    return;
+  }
+  if (mine) {
+    ChainEntry e;
+    e.k0 = k0;
+    e.k1 = k1;
+    e.meta = (uint64_t)n_ev | ((uint64_t)len << 8) | (first_extra << kChainEvOffShift);
+    e.ev0 = ev0;
+    tab[blk2->chain_base + (uint64_t)__popcll(rows & below(lane))] = e;
   }
 }
 
@@ -828,6 +931,55 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   d.special_code[1] = h_small[0] == ~0ull ? 0u : (uint32_t)h_small[1];
   d.blocks2 = blocks2;
   d.sb_abs = sb_abs;
+  d.chain_tab = nullptr;
+  d.chain_ev = nullptr;
+  if (raw.interval <= 64 && raw.n + 64 < kPosMask && !getenv("SBWT_NO_CHAIN_TAB")) {
+    // chain_tab (device_layout.h): entries for the rows sa_full + the text do not answer for.  A handful on a fully
+    // sorted index (the ends of the text); every row within `interval` positions above an LF-inconsistent one on an index
+    // whose suffix order stops at sort_len.  No table when they are more than a thirty-second of the rows of a large
+    // index (a damaged index: the walk itself remains, k_multi_bfs / k_multi).
+    DevTemp<uint64_t> chain_chunks;
+    DevTemp<unsigned long long> d_extra;
+    SBWT_HIP(chain_chunks.alloc(n_chunks + 1));
+    SBWT_HIP(d_extra.alloc(2));
+    SBWT_HIP(hipMemset(chain_chunks, 0, (n_chunks + 1) * sizeof(uint64_t)));
+    SBWT_HIP(hipMemset(d_extra, 0, 2 * sizeof(unsigned long long)));
+    k_chain_rows<<<grid_for(nb * 64, 256), 256>>>(d, blocks2);
+    k_chain_totals<<<(uint32_t)n_chunks, kChunk>>>(blocks2, nb, chain_chunks);
+    k_scan_chunks<<<1, 64>>>(chain_chunks, n_chunks + 1, 1);
+    k_chain_bases<<<(uint32_t)n_chunks, kChunk>>>(blocks2, nb, chain_chunks);
+    SBWT_LAUNCHED();
+    uint64_t n_chain = 0;
+    SBWT_HIP(hipMemcpy(&n_chain, chain_chunks + n_chunks, sizeof n_chain, hipMemcpyDeviceToHost));
+    const uint64_t chain_cap = std::max<uint64_t>(raw.n / 32, 1ull << 23);
+    ChainEntry* tab = nullptr;
+    uint64_t* evs = nullptr;
+    bool ok = n_chain > 0 && n_chain <= chain_cap;
+    unsigned long long h_extra = 0;
+    if (ok) {
+      k_chain_walk<false><<<grid_for(nb * 64, 256), 256>>>(d, nullptr, nullptr, d_extra);
+      SBWT_LAUNCHED();
+      SBWT_HIP(hipMemcpy(&h_extra, d_extra, sizeof h_extra, hipMemcpyDeviceToHost));
+      ok = h_extra <= 4 * chain_cap;
+    }
+    if (ok && (dev_alloc(ix, &tab, n_chain) || dev_alloc(ix, &evs, h_extra + 1))) {
+      (void)hipGetLastError();  // (no room: same results through the walk)
+      ok = false;
+    }
+    if (ok) {
+      k_chain_walk<true><<<grid_for(nb * 64, 256), 256>>>(d, tab, evs, d_extra + 1);
+      SBWT_LAUNCHED();
+      SBWT_HIP(hipDeviceSynchronize());
+      d.chain_tab = tab;
+      d.chain_ev = evs;
+    } else if (n_chain) {
+      k_chain_clear<<<grid_for(nb, 256), 256>>>(blocks2, nb);
+      SBWT_LAUNCHED();
+    }
+    if (getenv("SBWT_DEBUG"))
+      fprintf(stderr, "[sbwt debug] chain_tab: %llu of %llu rows need an entry, %llu further events: %s\n", (unsigned long long)n_chain,
+              (unsigned long long)raw.n, h_extra, d.chain_tab ? "built" : (n_chain ? "too many, none built" : "none needed"));
+  }
   {
     // widest order K <= 17 whose 4^K entries are at most 16 per suffix (beyond that nearly every K-mer that occurs
     // is a single row already) and whose table leaves kKmerHeadroom of this device's memory free (GRCh38: 17,

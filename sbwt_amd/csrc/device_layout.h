@@ -33,7 +33,9 @@ static_assert(sizeof(Block1) == 64, "Block1 is one 64-byte granule");
 struct alignas(128) Block2 {
   uint64_t plane[4];  // plane[k] bit j = bit k of code(64b + j)   (k = 0,1: y ; k = 2,3: x)
   uint32_t cnt[16];   // #code in bwt2[superblock start .. 64b)
-  uint64_t reserved[4];
+  uint64_t chain_rows;  // bit j: row 64b + j has an entry in chain_tab (below); rides in what the line had to spare
+  uint64_t chain_base;  // index in chain_tab of the first such row of this block
+  uint64_t reserved[2];
 };
 static_assert(sizeof(Block2) == 128, "Block2 is one 128-byte granule");
 constexpr int kSuperShift = 31;  // superblock = 2^31 positions, so relative counts fit 32 bits
@@ -79,6 +81,21 @@ constexpr uint32_t kHashSlots = 4;
 constexpr uint32_t kHashMaxOrder = 28;
 __host__ __device__ inline uint64_t hash_mix(uint64_t v, uint32_t order) { return (v * kHashMul) & ((1ull << (2 * order)) - 1ull); }
 
+// chain_tab: the depth-first locate of ONE row, memoised, for the rows sa_full + the text do not answer for (rows of
+// LF-inconsistent regions: an index whose ties beyond sort_len are unordered, as upstream's own builder leaves them).
+// find_possible (searcher.hpp:460-503) reaches the rows of a node from the rows of its parent through LF, base by base;
+// seen from ONE row i of the read's interval that is the chain r_0 = i, r_{d+1} = LF(r_d): the bases it prepends
+// (c_d = bwt[r_d]) say which node holds the chain at every depth, and every sampled r_d is a hit (depth d, position
+// d + SA[r_d]).  An entry = 32 bytes: the up to 63 bases of the chain (two words, first base most significant), meta =
+// number of events | chain length << 8 | index of the further events in chain_ev << 16, and the first event
+// (depth << 58 | position).  Where the tables are LF-consistent the chain is the text and has ONE event: those rows have
+// no entry.  multi_locate.h (k_multi_chain) puts a read's chains back together into upstream's emission order.
+struct ChainEntry {
+  uint64_t k0, k1, meta, ev0;
+};
+static_assert(sizeof(ChainEntry) == 32, "two 16-byte loads");
+constexpr uint64_t kChainEvOffShift = 16;
+
 constexpr int kPosBits = 40;
 constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
 constexpr uint64_t kRunMax = (1ull << (64 - kPosBits)) - 1;
@@ -111,6 +128,8 @@ struct DeviceIndex {
   uint32_t hash_complete;   // 1: EVERY prefix of hash_order bases whose upstream search interval is not empty has a slot (a located
                             // one, or a marker: run = 0) unless its two buckets are full -- a prefix that is in neither bucket while
                             // one of them has a free slot occurs nowhere: the read maps nowhere (device_index.hip, k_hash_cover)
+  const ChainEntry* chain_tab;  // null: none (device_layout.h above); indexed through Block2::chain_rows / chain_base
+  const uint64_t* chain_ev;     // events of the chains beyond their first
   const uint32_t* textrc;   // 2-bit text implied by the tables, reverse-complemented: textrc[x] = 3 - bwt[row of position n-1-x]
   // push_position tables (searcher.hpp:504-539)
   const uint64_t* chr_start; uint32_t n_chr;

@@ -228,47 +228,47 @@ __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, uint32_t lane_mask) {
 // pos0 (40 bits) | chr_id << 40 (16 bits) | is_rc << 56 | passed the filters << 57 | t << 58 (6 bits)
 constexpr uint64_t kPayOk = 1ull << 57;
 
-// What the sort of one read's rows works on (LDS of the team): the full keys k0 | k1 (prepended bases, first base most
-// significant, zero padded) and pay (t in the top six bits) of rows 0 .. m-1, padding rows m .. N-1 all ones, the sort
-// words key[i] = (k0[i] & ~0xFFFF) | i, two order buffers and the reduction scratch of the workgroup.
+// What the sort of one read's entries works on (LDS of the team).  An entry is one reported hit of the read: the bases
+// its node prepended (ka[i].x | ka[i].y: first base most significant, zero padded) and pay[i] (depth t in the top six bits).
 struct SortLds {
-  uint64_t *k0, *k1, *key, *pay;
-  uint16_t *ord_a, *ord_b;
+  ulonglong2 *ka, *kb;  // the full keys; a second buffer of the same size (merge passes; the radix path's counters)
+  uint16_t *ta, *tb;    // t << 10 | entry index: the tail of the sort key, and what the sort returns in order
+  uint64_t* pay;
   uint64_t (*red)[5];
   uint32_t* scan;
 };
+constexpr uint32_t kOrdMask = 1023u;  // entry index of an element of the returned order
+struct SortedRows {
+  const uint16_t* ord;     // entry at place k = ord[k] & kOrdMask
+  const ulonglong2* keys;  // its full key = keys[k]; null: ka[ord[k] & kOrdMask] (the merge passes move the keys, the radix passes do not)
+};
+__device__ __forceinline__ ulonglong2 sorted_key(const SortedRows& R, const SortLds& S, uint32_t k) {
+  return R.keys ? R.keys[k] : S.ka[R.ord[k] & kOrdMask];
+}
 
-// Puts the rows of one read in emission order: full key (k0, k1, t) ascending, ties in row order.  or0 .. andt: OR and
-// AND of the key words over the calling thread's rows.  Returns the order as ord[k] = row at place k (k < m), or null
-// when it is key[k] & 0xFFFF.  Every thread of the team calls it.
+// Puts the m entries of one read in emission order: full key (ka.x, ka.y, t) ascending, ties in entry order (the entries
+// of one node are numbered in row order).  or0 .. andt: OR and AND of the key words over the calling thread's entries.
+// Returns the order (SortedRows); ka and kb do not keep their contents.  Every thread of the team calls it.
+//
+// Two ways.  (1) Few 8-bit digits of the key differ between the entries (copies of a repeat share most of their left
+// context): one stable counting pass per differing digit.  (2) Otherwise a merge sort whose merges are done by RANK:
+// every element of two sorted runs finds its place in the merged run by a binary search over the other run -- log2(run)
+// + 1 dependent LDS reads, four independent searches per thread in flight, ONE synchronisation per level and no
+// data-dependent branch.  (The bitonic network this replaces made log^2 passes of compare-EXCHANGES, each a dependent
+// read-compare-write round trip through LDS with a second round trip for entries whose first 24 bases tie -- diverged
+// repeat copies tie all the time: 1,800 clocks per pass, 58-77 % of k_multi_sort on a repeat-rich genome.)
 template <int T>
-__device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint32_t m, uint32_t N, uint32_t tid, uint32_t lane,
+__device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t m, uint32_t tid, uint32_t lane,
                                                           uint64_t or0, uint64_t and0, uint64_t or1, uint64_t and1, uint32_t ort,
                                                           uint32_t andt, bool& used_radix) {
   constexpr uint32_t kCap = kSortMax / (256 / T);
-  constexpr uint32_t kWaveRows = kCap / 64;  // 64-row groups of a team's rows: the unit the radix passes rank in
-  uint64_t* const k0 = S.k0;
-  uint64_t* const k1 = S.k1;
-  uint64_t* const key = S.key;
+  constexpr uint32_t kWaveRows = kCap / 64;  // 64-entry groups of a team's entries: the unit the radix passes rank in
+  ulonglong2* const ka = S.ka;
   uint64_t* const pay = S.pay;
-  uint16_t* const ord_a = S.ord_a;
-  uint16_t* const ord_b = S.ord_b;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
-  // full order of two rows given their offsets: prepended string (zero padded), its length, the offset
-  auto row_less = [&](uint32_t ia, uint32_t ib) -> bool {
-    // all six words first: one LDS round trip instead of three
-    const uint64_t a0 = k0[ia], b0 = k0[ib], a1 = k1[ia], b1 = k1[ib];
-    const uint32_t ta = (uint32_t)(pay[ia] >> 58), tb = (uint32_t)(pay[ib] >> 58);
-    if (a0 != b0) return a0 < b0;
-    if (a1 != b1) return a1 < b1;
-    if (ta != tb) return ta < tb;
-    return ia < ib;
-  };
-  // Which 8-bit digits of the full key -- k0 | k1 | t, 17 digits -- differ between the rows of this read?  The
-  // emission order is the order of the full keys with ties in row order, i.e. what a STABLE sort by those digits
-  // alone gives.  Copies of a repeat share most of their left context (the repeat itself), so few digits
-  // differ: one stable counting pass per differing digit, least significant first, instead of a comparison
-  // sort whose every comparison of two such rows has to go through the full keys.
+  // Which 8-bit digits of the full key -- k0 | k1 | t, 17 digits -- differ between the entries of this read?  The
+  // emission order is the order of the full keys with ties in entry order, i.e. what a STABLE sort by those digits
+  // alone gives.
   bool radix;
   uint32_t dmask = 0;  // bit d: digit d differs (0 = the first four bases ... 15 = bases 60..63, 16 = t)
   {
@@ -297,17 +297,16 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
     dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)dmask);
     radix = __popc(dmask) <= (int)kRadixMaxPasses;
   }
-  const uint16_t* ord = nullptr;  // radix path: row offsets in emission order
   used_radix = radix;
   if (radix) {
-    uint16_t* oin = ord_a;
-    uint16_t* oout = ord_b;
+    uint16_t* oin = S.ta;
+    uint16_t* oout = S.tb;
     for (uint32_t k = tid; k < m; k += T) oin[k] = (uint16_t)k;
     team_sync<T>();
-    uint16_t* const h16 = reinterpret_cast<uint16_t*>(key);  // [256 digits][kWaveRows]: the sort words are not needed here
+    uint16_t* const h16 = reinterpret_cast<uint16_t*>(S.kb);  // [256 digits][kWaveRows] counters
     for (int d = 16; d >= 0; --d) {
       if (!((dmask >> d) & 1u)) continue;
-      for (uint32_t k = tid; k < kCap * 2u; k += T) reinterpret_cast<uint32_t*>(key)[k] = 0u;
+      for (uint32_t k = tid; k < kCap * 2u; k += T) reinterpret_cast<uint32_t*>(S.kb)[k] = 0u;
       team_sync<T>();
       uint32_t dig[4], rnk[4], idx[4];
 #pragma unroll
@@ -319,9 +318,9 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
         if (valid) {
           idx[kk] = oin[j];
           dig[kk] = d == 16 ? (uint32_t)(pay[idx[kk]] >> 58)
-                            : (uint32_t)((d >= 8 ? k1[idx[kk]] : k0[idx[kk]]) >> (56 - 8 * (d & 7))) & 0xFFu;
+                            : (uint32_t)((d >= 8 ? ka[idx[kk]].y : ka[idx[kk]].x) >> (56 - 8 * (d & 7))) & 0xFFu;
         }
-        // lanes of this 64-row group with the same digit; a row's place among them
+        // lanes of this 64-entry group with the same digit; an entry's place among them
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -335,7 +334,7 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
       team_sync<T>();
       {
         // exclusive prefix sums in (digit, group) order: 16 consecutive counters per thread, then over threads
-        uint4* hq = reinterpret_cast<uint4*>(key) + 2u * tid;
+        uint4* hq = reinterpret_cast<uint4*>(S.kb) + 2u * tid;
         uint4 qa = hq[0], qb = hq[1];
         uint32_t w8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
         uint32_t run = 0;
@@ -371,21 +370,23 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
       team_sync<T>();
       uint16_t* const sw = oin; oin = oout; oout = sw;
     }
-    ord = oin;
-    N = 0;
+    return SortedRows{oin, nullptr};
   }
-  if (!radix) {
-  // Rows whose left contexts agree over their whole length (copies of a repeat at the same phase of the
-  // sampling, say) are in emission order as they stand, and every comparison among them would take the
-  // full-key path: one pass finds out whether the words are in order already.
+  // ---- merge sort by rank
+  const ulonglong2* src = S.ka;
+  ulonglong2* dst = S.kb;
+  uint16_t* ts = S.ta;
+  uint16_t* td = S.tb;
+  for (uint32_t k = tid; k < m; k += T) ts[k] = (uint16_t)(((uint32_t)(pay[k] >> 58) << 10) | k);
+  team_sync<T>();
+  auto elem_less = [](const ulonglong2& a, uint32_t at, const ulonglong2& b, uint32_t bt) -> bool {
+    return a.x < b.x || (a.x == b.x && (a.y < b.y || (a.y == b.y && at < bt)));
+  };
   {
+    // Entries whose left contexts agree over their whole length (copies of a repeat at the same phase of the sampling,
+    // say) are in emission order as they stand: one pass finds out
     bool in_order = true;
-    for (uint32_t i = tid; i + 1 < N; i += T) {
-      const uint64_t ka = key[i], kb = key[i + 1];
-      bool less = ka < kb;
-      if (((ka ^ kb) >> 16) == 0) less = row_less((uint32_t)ka & 0xFFFFu, (uint32_t)kb & 0xFFFFu);
-      in_order = in_order && less;
-    }
+    for (uint32_t i = tid; i + 1 < m; i += T) in_order = in_order && elem_less(src[i], ts[i], src[i + 1], ts[i + 1]);
     const bool wave_ok = __all(in_order);
     if (T == 256) {
       if (lane == 0) S.scan[threadIdx.x >> 6] = wave_ok ? 1u : 0u;
@@ -395,25 +396,47 @@ __device__ __forceinline__ const uint16_t* team_sort_rows(const SortLds& S, uint
     } else {
       in_order = wave_ok;
     }
-    if (in_order) N = 0;  // nothing to sort
+    if (in_order) return SortedRows{ts, src};
   }
-  // bitonic sort of the N words in LDS; the full keys are looked up only for words whose first 24 bases agree
-  for (uint32_t size = 2; size <= N; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t t = tid; t < (N >> 1); t += T) {
-        const uint32_t i = 2 * t - (t & (stride - 1));  // lower index of the pair
-        const uint32_t j = i + stride;
-        const bool up = (i & size) == 0;
-        const uint64_t ka = key[i], kb = key[j];
-        bool b_less = kb < ka;
-        if (((ka ^ kb) >> 16) == 0) b_less = row_less((uint32_t)kb & 0xFFFFu, (uint32_t)ka & 0xFFFFu);
-        if (b_less == up) { key[i] = kb; key[j] = ka; }
+  for (uint32_t R = 1; R < m; R <<= 1) {  // sorted runs of R elements -> of 2R
+    ulonglong2 e[4];
+    uint32_t et[4], ob[4], olen[4], cnt[4], dbase[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t x = tid + (uint32_t)kk * T;
+      ob[kk] = 0; olen[kk] = 0; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0;
+      e[kk] = make_ulonglong2(0, 0);
+      if (x < m) {
+        e[kk] = src[x];
+        et[kk] = ts[x];
+        const uint32_t pair_base = x & ~(2u * R - 1u);
+        const uint32_t other = pair_base + ((x & R) ? 0u : R);  // the run this element is merged with
+        dbase[kk] = pair_base + (x & (R - 1u));
+        if (other < m) { ob[kk] = other; olen[kk] = m - other < R ? m - other : R; }
       }
-      team_sync<T>();
     }
+    // elements of the other run below this one (keys are distinct: the entry index is part of them), by binary lifting
+    for (uint32_t step = R; step; step >>= 1) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t c = cnt[kk] + step;
+        const bool in = c <= olen[kk];
+        const uint32_t o = ob[kk] + (in ? c - 1u : 0u);
+        const ulonglong2 v = src[o];
+        const uint32_t vt = ts[o];
+        if (in && elem_less(v, vt, e[kk], et[kk])) cnt[kk] = c;
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t x = tid + (uint32_t)kk * T;
+      if (x < m) { dst[dbase[kk] + cnt[kk]] = e[kk]; td[dbase[kk] + cnt[kk]] = (uint16_t)et[kk]; }
+    }
+    team_sync<T>();
+    const ulonglong2* const s1 = src; src = dst; dst = const_cast<ulonglong2*>(s1);
+    uint16_t* const t1 = ts; ts = td; td = t1;
   }
-  }
-  return ord;
+  return SortedRows{ts, src};
 }
 
 // -DSBWT_PHASE_CLOCKS: thread 0 of every team adds the clocks each phase of a read took to g_multi_phase[] (a
@@ -453,12 +476,13 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
                                                                         const unsigned long long* __restrict__ queue_count) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;       // hits a team holds
-  __shared__ __attribute__((aligned(16))) uint64_t s_k0[kSortMax], s_k1[kSortMax], s_pay[kSortMax];
+  __shared__ __attribute__((aligned(16))) ulonglong2 s_ka[kSortMax];
+  __shared__ __attribute__((aligned(16))) uint64_t s_pay[kSortMax];
   // Per team, one region used twice: while the walk runs, the two frontiers -- a node is its first row | rows << 40 and
   // the bases prepended so far (first base most significant) --; once it is over, what the sort and the cut need
-  // (sort words, two order buffers, the row at every place, accepted hits before every place).  The kernel is bound by
-  // the latency of 63 dependent levels per read: LDS per team decides how many reads a CU has in flight.
-  constexpr uint32_t kFrontierBytes = 2u * 3u * kNodes * 8u, kSortBytes = kCap * (8u + 4u * 2u);
+  // (the second key buffer, two order buffers, the row at every place, accepted hits before every place).  The kernel is
+  // bound by the latency of 63 dependent levels per read: LDS per team decides how many reads a CU has in flight.
+  constexpr uint32_t kFrontierBytes = 2u * 3u * kNodes * 8u, kSortBytes = kCap * (16u + 4u * 2u);
   constexpr uint32_t kRawTeam = kFrontierBytes > kSortBytes ? kFrontierBytes : kSortBytes;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTeams * kRawTeam];
   __shared__ uint64_t s_red_all[4][5];
@@ -483,18 +507,16 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     t_chr = s_chr; t_nk = s_nk; t_nv = s_nv;
   }
   const uint32_t team = threadIdx.x / T, tid = threadIdx.x % T, lane = threadIdx.x & 63;
-  uint64_t* k0 = s_k0 + team * kCap;
-  uint64_t* k1 = s_k1 + team * kCap;
+  ulonglong2* ka = s_ka + team * kCap;
   unsigned char* const raw = s_raw + team * kRawTeam;
   uint64_t* const fr = reinterpret_cast<uint64_t*>(raw);  // [2][3][kNodes]
-  uint64_t* key = reinterpret_cast<uint64_t*>(raw);
-  uint16_t* const ord0 = reinterpret_cast<uint16_t*>(raw + kCap * 8u);
+  uint16_t* const ord0 = reinterpret_cast<uint16_t*>(raw + kCap * 16u);
   uint64_t* pay = s_pay + team * kCap;
   uint16_t* idx_of = ord0 + 2u * kCap;
   uint16_t* acc_of = ord0 + 3u * kCap;
   uint32_t* cnt = s_cnt_all[team];
   uint8_t* const pruned = s_pruned_all[team];
-  const SortLds sort_lds{k0, k1, key, pay, ord0, ord0 + kCap, s_red_all, s_scan_all};
+  const SortLds sort_lds{ka, reinterpret_cast<ulonglong2*>(raw), ord0, ord0 + kCap, pay, s_red_all, s_scan_all};
   if (ix.interval > 64 || ix.n_chr > 0xFFFFu) return;  // key / payload fields too narrow: k_multi
   const uint64_t qn = *queue_count;
 #ifdef SBWT_PHASE_CLOCKS
@@ -537,7 +559,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
           if (h.pos0 > kPosMask) cnt[2] = 1u;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
           py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
         }
-        k0[at] = p0; k1[at] = p1; pay[at] = py;
+        ka[at] = make_ulonglong2(p0, p1); pay[at] = py;
         ++at;
       }
     }
@@ -668,7 +690,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
                 if (h.pos0 > kPosMask) cnt[2] = 1u;
                 py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
               }
-              k0[at] = p0; k1[at] = p1; pay[at] = py;
+              ka[at] = make_ulonglong2(p0, p1); pay[at] = py;
               ++at;
             }
           }
@@ -690,23 +712,16 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     if (over) continue;  // outgrew the team: the read stays queued for k_multi (team-uniform: snapshotted between syncs)
     const uint32_t H = cnt[0];
     // ---- emission order
-    uint32_t N = 64;
-    while (N < H && N < kCap) N <<= 1;
     uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
     uint32_t ort = 0, andt = ~0u;
-    for (uint32_t i = tid; i < N; i += T) {
-      if (i < H) {
-        const uint64_t h0 = k0[i], h1 = k1[i];
-        const uint32_t t = (uint32_t)(pay[i] >> 58);
-        or0 |= h0; and0 &= h0; or1 |= h1; and1 &= h1; ort |= t; andt &= t;
-      } else {
-        k0[i] = ~0ull; k1[i] = ~0ull; pay[i] = 63ull << 58;
-      }
-      key[i] = (k0[i] & ~0xFFFFull) | i;
+    for (uint32_t i = tid; i < H; i += T) {
+      const ulonglong2 h = ka[i];
+      const uint32_t t = (uint32_t)(pay[i] >> 58);
+      or0 |= h.x; and0 &= h.x; or1 |= h.y; and1 &= h.y; ort |= t; andt &= t;
     }
-    team_sync<T>();
+    team_sync<T>();  // (the frontiers in the team's region are dead: the sort takes it over)
     bool radix = false;
-    const uint16_t* ord = team_sort_rows<T>(sort_lds, H, N, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+    const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, ort, andt, radix);
     SBWT_PHASE(4);
     // ---- accepted hits before every place, node boundaries, the cut
     uint32_t base = 0;
@@ -715,7 +730,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
       uint32_t i = 0;
       bool ok = false;
       if (k < H) {
-        i = ord ? (uint32_t)ord[k] : ((uint32_t)key[k] & 0xFFFFu);
+        i = sorted.ord[k] & kOrdMask;
         ok = (pay[i] & kPayOk) != 0;
         idx_of[k] = (uint16_t)i;
       }
@@ -738,7 +753,8 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     const uint64_t maybe = (uint64_t)(int64_t)(int32_t)(uint32_t)m;  // (searcher.hpp:412,464: an int against a size_t)
     for (uint32_t k = tid + 1; k < H; k += T) {
       const uint32_t ia = idx_of[k - 1], ib = idx_of[k];
-      const bool boundary = k0[ia] != k0[ib] || k1[ia] != k1[ib] || (pay[ia] >> 58) != (pay[ib] >> 58);
+      const ulonglong2 qa = sorted_key(sorted, sort_lds, k - 1), qb = sorted_key(sorted, sort_lds, k);
+      const bool boundary = qa.x != qb.x || qa.y != qb.y || (pay[ia] >> 58) != (pay[ib] >> 58);
       if (boundary && (uint64_t)acc_of[k] == maybe) atomicMin(&cnt[3], k);
     }
     team_sync<T>();
@@ -776,14 +792,15 @@ template <int T, bool kLds>  // kLds: the filter tables are staged in LDS (a com
 __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, const MultiSortArgs a) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;  // rows a team can sort
-  // what is sorted is one 64-bit word per row: the first 24 prepended bases (48 bits) over the row's offset in
-  // the interval (16 bits).  Rows whose first 24 bases agree are compared in full through the offset (rare).
-  __shared__ __attribute__((aligned(16))) uint64_t s_k0[kSortMax], s_k1[kSortMax], s_key[kSortMax], s_pay[kSortMax];
+  // what is sorted: per row the full key (the up to 63 prepended bases, 16 bytes) and a 16-bit tail (depth | row); two
+  // buffers of each (team_sort_rows)
+  __shared__ __attribute__((aligned(16))) ulonglong2 s_ka[kSortMax], s_kb[kSortMax];
+  __shared__ __attribute__((aligned(16))) uint64_t s_pay[kSortMax];
   __shared__ uint32_t s_list_all[256];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_bad_all[4];
-  __shared__ uint16_t s_ord_all[2][kSortMax];  // radix path: row offsets in emission order so far, ping-pong
-  __shared__ uint64_t s_red_all[4][5];          // radix path: OR / AND of the key words over a wave's rows
+  __shared__ uint16_t s_ord_all[2][kSortMax];
+  __shared__ uint64_t s_red_all[4][5];          // OR / AND of the key words over a wave's rows
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];  // (n_chr + 2 n_npos) words when a.lds_tables
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
   // push_position tables: LDS copies when they fit
@@ -805,15 +822,11 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   team_sync<T>();
   unsigned long long ph_t = clock64();
 #endif
-  uint64_t* k0 = s_k0 + team * kCap;
-  uint64_t* k1 = s_k1 + team * kCap;
-  uint64_t* key = s_key + team * kCap;
+  ulonglong2* ka = s_ka + team * kCap;
   uint64_t* pay = s_pay + team * kCap;
   uint32_t* list = s_list_all + team * T;
   uint32_t* s_bad = s_bad_all + team;
-  uint16_t* ord_a = s_ord_all[0] + team * kCap;
-  uint16_t* ord_b = s_ord_all[1] + team * kCap;
-  const SortLds sort_lds{k0, k1, key, pay, ord_a, ord_b, s_red_all, s_scan_all};
+  const SortLds sort_lds{ka, s_kb + team * kCap, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, pay, s_red_all, s_scan_all};
   const uint64_t m_text = ix.n - 1;
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
   // teams stride over the waves of the search kernel; each wave queued its reads at queue[w * chunk ..)
@@ -856,8 +869,6 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
         res.first_hit += a.multi_base + wi.slots;  // wave-relative until now
         if (tid == 0) *s_bad = (m > kCap || no_sort_path) ? 1u : 0u;
         team_sync<T>();
-        uint32_t N = 64;
-        while (N < m && N < kCap) N <<= 1;
         SBWT_PHASE_MEM(1);
         uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;  // over this thread's rows: which key bits differ
         uint32_t ort = 0, andt = ~0u;
@@ -918,7 +929,6 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint32_t i = tid + (uint32_t)kk * T;
-            if (i >= N) continue;
             uint64_t h0 = ~0ull, h1 = ~0ull, py = 63ull << 58;
             if (i < m) {
               const uint64_t e = e4[kk];
@@ -944,8 +954,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
                 or0 |= h0; and0 &= h0; or1 |= h1; and1 &= h1; ort |= t; andt &= t;
               }
             }
-            k0[i] = h0; k1[i] = h1; pay[i] = py;
-            key[i] = (h0 & ~0xFFFFull) | i;  // padding rows: all ones, behind every real row
+            if (i < m) { ka[i] = make_ulonglong2(h0, h1); pay[i] = py; }
           }
         }
         team_sync<T>();
@@ -959,7 +968,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
           continue;
         }
         bool radix = false;
-        const uint16_t* ord = team_sort_rows<T>(sort_lds, (uint32_t)m, N, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+        const SortedRows sorted = team_sort_rows<T>(sort_lds, (uint32_t)m, tid, lane, or0, and0, or1, and1, ort, andt, radix);
         SBWT_PHASE(6);
         // rows in emission order: compact those that passed the filters, write
         sbwt_hit* out = a.hits + res.first_hit;
@@ -967,7 +976,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
         for (uint32_t c = 0; c < m; c += T) {
           const uint32_t k = c + tid;
           uint64_t py = 0;
-          if (k < m) py = pay[ord ? (uint32_t)ord[k] : ((uint32_t)key[k] & 0xFFFFu)];
+          if (k < m) py = pay[sorted.ord[k] & kOrdMask];
           const bool ok = (py & kPayOk) != 0;
           sbwt_hit h;
           h.pos0 = py & kPosMask;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (one rocprofv3 run each, counters only) over the kernels matching a regex, at bench scale.
-# usage (GPU box): bash tools/pmc_kernel.sh OUTDIR KERNEL_REGEX [bench args...]
+# usage (GPU box): [PMC_PASSES="1 2 5"] bash tools/pmc_kernel.sh OUTDIR KERNEL_REGEX [bench args...]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/$1; RX=$2; shift; shift
@@ -14,6 +14,7 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_I
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   n=$((n+1))
+  if [ -n "${PMC_PASSES:-}" ] && ! [[ " $PMC_PASSES " == *" $n "* ]]; then continue; fi   # PMC_PASSES="1 2 4": only those passes
   timeout -s KILL 300 rocprofv3 --pmc $pass --kernel-include-regex "$RX" --output-format csv -d $OUT/p$n -o bench -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu --no-extras "$@" > $OUT/p$n.json 2> $OUT/p$n.err || { echo "pass $n ($pass) failed"; tail -3 $OUT/p$n.err; }
 done
 python3 - $OUT "$RX" "$*" <<'PY'
