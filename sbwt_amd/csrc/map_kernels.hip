@@ -43,6 +43,7 @@ struct Counters {
   unsigned long long shared_count;    // multi-hit reads whose record points at the list of another read with the same interval (k_multi_share)
   unsigned long long bfs_count;       // reads of the depth-first queue located level by level (k_multi_bfs); the rest took k_multi
   unsigned long long absent_count;    // reads the fast pass settled because their prefix occurs nowhere (DeviceIndex::hash_complete)
+  unsigned long long chain_count;     // reads of the depth-first queue located from memoised chains (k_multi_chain)
 };
 
 struct MapArgs {
@@ -165,7 +166,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 11;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 12;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -187,12 +188,13 @@ struct MapWork {
   uint32_t group_slots = 0;                   // a power of two; 0: no grouping (the no-allocation entry point)
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // null: the pass is not timed
   // test knobs (environment variables, read ONCE: when the ctx is made, or -- the entry point without a ctx -- the index)
-  bool no_bfs = false;
+  bool no_bfs = false, no_chain = false;
   uint32_t ring_width_max = (uint32_t)kRingWidthMax, ring_chr_max = 0xFFFFu;
 };
 
-static void read_pass_knobs(bool* no_bfs, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
+static void read_pass_knobs(bool* no_bfs, bool* no_chain, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
   *no_bfs = getenv("SBWT_NO_BFS") != nullptr;
+  *no_chain = getenv("SBWT_NO_CHAIN") != nullptr;
   *ring_width_max = debug_knob("SBWT_DEBUG_RING_WIDTH", (uint32_t)kRingWidthMax);
   *ring_chr_max = debug_knob("SBWT_DEBUG_RING_CHR", 0xFFFFu);
 }
@@ -203,7 +205,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -264,7 +266,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (!c) return SBWT_ERR_NOMEM;
   c->ix = ix;
   c->max_reads = max_reads;
-  read_pass_knobs(&c->no_bfs, &c->ring_width_max, &c->ring_chr_max);
+  read_pass_knobs(&c->no_bfs, &c->no_chain, &c->ring_width_max, &c->ring_chr_max);
   c->no_settle = getenv("SBWT_NO_SETTLE") != nullptr;
   c->no_direct = getenv("SBWT_NO_DIRECT") != nullptr;
   if (const char* sb = getenv("SBWT_SUBBATCH")) c->subbatch = strtoull(sb, nullptr, 10);
@@ -529,6 +531,16 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
       k_multi_sort<256, false><<<w.grid_sort, 256, 0, w.stream>>>(d, ms);
     }
     SBWT_LAUNCHED();
+    if (d.chain_tab && !w.no_chain) {  // the reads k_multi_sort handed on, from memoised chains (multi_locate.h); what it leaves stays queued
+      if (w.sort_lds_bytes) {
+        k_multi_chain<64, true><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count, &w.d_ctr->chain_count);
+        k_multi_chain<256, true><<<w.grid_sort, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count, &w.d_ctr->chain_count);
+      } else {
+        k_multi_chain<64, false><<<w.grid_sort, 256, 0, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count, &w.d_ctr->chain_count);
+        k_multi_chain<256, false><<<w.grid_sort, 256, 0, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count, &w.d_ctr->chain_count);
+      }
+      SBWT_LAUNCHED();
+    }
     if (!w.no_bfs) {  // the same walk level by level, a team per read (multi_locate.h); k_multi takes what is left
       k_multi_bfs<64, 64><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
       k_multi_bfs<256, 512><<<w.grid_bfs, 256, w.sort_lds_bytes, w.stream>>>(d, ms, w.d_dfs_queue, &w.d_ctr->dfs_count);
@@ -576,6 +588,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     stats_out[5] = (accumulate ? stats_out[5] : 0) + w.h_ctr->hash_stats[1];
     stats_out[8] = (accumulate ? stats_out[8] : 0) + w.h_ctr->shared_count;
     stats_out[9] = (accumulate ? stats_out[9] : 0) + w.h_ctr->bfs_count;
+    stats_out[11] = (accumulate ? stats_out[11] : 0) + w.h_ctr->chain_count;
   }
   *multi_used = w.h_ctr->hit_count;
   if (wide_used) *wide_used = w.h_ctr->wide_count;
@@ -692,7 +705,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     SBWT_LAUNCHED();
     const ResultIO io2 = plain ? ResultIO{c->d_pend_res, nullptr, nullptr, 0, c->d_pend_hits} : ResultIO{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
@@ -707,13 +720,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent, st[11]};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent, 0};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }
@@ -925,7 +938,7 @@ int sbwt::finish_index(sbwt_index* ix) {
   ix->plan.sm_lds_bytes = w.sm_lds_bytes;
   ix->plan.sm_ring_bytes = w.sm_ring_bytes;
   ix->plan.sort_lds_bytes = w.sort_lds_bytes;
-  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
+  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.no_chain, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
   return SBWT_OK;
 }
 
@@ -985,6 +998,7 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
   w.sm_ring_bytes = ix->plan.sm_ring_bytes;
   w.sort_lds_bytes = ix->plan.sort_lds_bytes;
   w.no_bfs = ix->plan.no_bfs;
+  w.no_chain = ix->plan.no_chain;
   w.ring_width_max = ix->plan.ring_width_max;
   w.ring_chr_max = ix->plan.ring_chr_max;
   if (!w.grid_sort || !w.sm_ring_bytes) {

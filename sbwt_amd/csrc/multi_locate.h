@@ -1012,4 +1012,242 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
 #endif
 }
 
+
+// ---- k_multi_chain: the depth-first locate put together from memoised chains -------------------------------------
+//
+// For the reads k_multi_sort hands on because a row lies outside an LF-consistent region.  find_possible
+// (searcher.hpp:460-503) reaches the rows of a node from the rows of its parent through LF, one base at a time, and LF
+// restricted to the rows of one base keeps their order: so the node the walk holds after prepending the bases w is
+// exactly { LF^|w|(i) : i a row of the read's interval whose chain spells w }, in the order of the rows i.  A row's
+// chain does not depend on the read: chain_tab (device_layout.h) holds it for the rows the text does not answer for,
+// the text IS the chain of the others.  What the walk reports is then, per row, its events (depth d, position) --
+// sampled rows on its chain -- and its order falls out of the chains:
+//  * emission order = pre-order over the prepended strings, A < C < G < T, rows of one node in row order: the events
+//    sorted by (first d bases of the chain, d), ties in row order (team_sort_rows; entries are numbered in row order);
+//  * a node of ONE row that is sampled has no children (searcher.hpp:495): an event at depth d >= 1 of a chain whose
+//    first d bases no other chain of the read shares (no other row passes through that node) ends the chain there;
+//  * the early exit (searcher.hpp:464) and SBWT_RF_TRUNCATED: as in k_multi_bfs, on the sorted list.
+// A read whose entries outgrow the team, or with a row chain_tab does not hold, stays queued for k_multi_bfs / k_multi.
+template <int T, bool kLds>
+__global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, const MultiSortArgs a, uint32_t* __restrict__ queue,
+                                                        const unsigned long long* __restrict__ queue_count,
+                                                        unsigned long long* __restrict__ chain_count) {
+  constexpr uint32_t kTeams = 256 / T;
+  constexpr uint32_t kCap = kSortMax / kTeams;  // rows, and entries, a team holds
+  __shared__ __attribute__((aligned(16))) ulonglong2 s_ka[kSortMax], s_kb[kSortMax];
+  __shared__ __attribute__((aligned(16))) uint64_t s_pay[kSortMax];
+  __shared__ uint16_t s_ord_all[2][kSortMax];
+  __shared__ uint16_t s_acc_all[kSortMax];
+  __shared__ uint8_t s_len_all[kSortMax];
+  __shared__ uint64_t s_red_all[4][5];
+  __shared__ uint32_t s_scan_all[4];
+  __shared__ uint32_t s_cnt_all[kTeams][4];  // [0] fail, [1] cut
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
+  if (*a.overflow) return;
+  if (!ix.chain_tab || ix.interval > 64 || ix.n_chr > 0xFFFFu) return;
+  const uint64_t *t_chr = ix.chr_start, *t_nk = ix.npos_key, *t_nv = ix.npos_val;
+  if (kLds) {
+    uint64_t* s_chr = s_tab;
+    uint64_t* s_nk = s_chr + ix.n_chr;
+    uint64_t* s_nv = s_nk + ix.n_npos;
+    for (uint32_t k = threadIdx.x; k < ix.n_chr; k += blockDim.x) s_chr[k] = ix.chr_start[k];
+    for (uint32_t k = threadIdx.x; k < ix.n_npos; k += blockDim.x) { s_nk[k] = ix.npos_key[k]; s_nv[k] = ix.npos_val[k]; }
+    __syncthreads();
+    t_chr = s_chr; t_nk = s_nk; t_nv = s_nv;
+  }
+  const uint32_t team = threadIdx.x / T, tid = threadIdx.x % T, lane = threadIdx.x & 63;
+  ulonglong2* const ka = s_ka + team * kCap;
+  ulonglong2* const kb = s_kb + team * kCap;  // before the sort: the whole chain of every row
+  uint64_t* const pay = s_pay + team * kCap;
+  uint16_t* const acc_of = s_acc_all + team * kCap;
+  uint8_t* const len_of = s_len_all + team * kCap;
+  uint32_t* const cnt = s_cnt_all[team];
+  const SortLds sort_lds{ka, kb, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, pay, s_red_all, s_scan_all};
+  const uint64_t qn = *queue_count;
+  const uint64_t m_text = ix.n - 1;
+  const uint32_t depth_max = (uint32_t)ix.interval - 1u;  // bases a chain can hold
+  // the first d bases of a chain (d <= 63), zero padded
+  auto prefix_of = [](ulonglong2 f, uint32_t d) -> ulonglong2 {
+    if (d == 0) return make_ulonglong2(0, 0);
+    if (d < 32u) return make_ulonglong2(f.x & (~0ull << (64u - 2u * d)), 0);
+    if (d == 32u) return make_ulonglong2(f.x, 0);
+    return make_ulonglong2(f.x, f.y & (~0ull << (64u - 2u * (d - 32u))));
+  };
+  // wave-level exclusive scan; *total = sum over the team (T == 256: through s_scan_all, two barriers)
+  auto team_excl_scan = [&](uint32_t v, uint32_t* total) -> uint32_t {
+    uint32_t inc = v;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, sft);
+      if (lane >= (uint32_t)sft) inc += o;
+    }
+    uint32_t base = inc - v, tot = (uint32_t)__shfl((int)inc, 63);
+    if (T == 256) {
+      const uint32_t wave = threadIdx.x >> 6;
+      __syncthreads();
+      if (lane == 63) s_scan_all[wave] = inc;
+      __syncthreads();
+      tot = s_scan_all[0] + s_scan_all[1] + s_scan_all[2] + s_scan_all[3];
+      for (uint32_t v2 = 0; v2 < wave; ++v2) base += s_scan_all[v2];
+    }
+    *total = tot;
+    return base;
+  };
+
+  for (uint64_t q = (uint64_t)blockIdx.x * kTeams + team; q < qn; q += (uint64_t)gridDim.x * kTeams) {
+    const uint32_t r = queue[q];
+    if (r == kQueueDone) continue;  // (team-uniform)
+    const MultiRead res = rio_load(a.io, r);  // first_hit is global by now (k_multi_sort)
+    const uint64_t lo = res.lo, m64 = res.hi - res.lo;
+    if (m64 > kCap) continue;
+    const uint32_t m = (uint32_t)m64;
+    const uint32_t L = a.lens[r];
+    team_sync<T>();  // the previous read is done with the team's LDS
+    if (tid < 4) cnt[tid] = 0;
+    // ---- the chains of this thread's rows: rows 4 tid .. 4 tid + 3 (consecutive, so that entries numbered thread by
+    // thread are numbered in row order)
+    ulonglong2 full[4];
+    uint64_t ev0[4], meta[4];
+    uint32_t n_ev[4], len[4];
+    bool fail = false;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t i = 4u * tid + (uint32_t)kk;
+      full[kk] = make_ulonglong2(0, 0);
+      ev0[kk] = 0; meta[kk] = 0; n_ev[kk] = 0; len[kk] = 0;
+      if (i >= m) continue;
+      const uint64_t row = lo + i;
+      const uint64_t e = ix.sa_full[row];
+      const uint64_t p = e & kPosMask;
+      const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
+      if (e != kNoPosition && (e >> kPosBits) >= need) {
+        // the text is the chain: bases text[p - 1], text[p - 2], ... = 3 - textrc[x0 ..], one event at depth p mod interval
+        const uint64_t x0 = m_text - p;
+        const uint4* tx = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
+        const uint4 w0 = tx[0], w1 = tx[1];
+        uint64_t c0, c1;
+        sm_funnel128(u64_of(w0.x, w0.y), u64_of(w0.z, w0.w), u64_of(w1.x, w1.y), u64_of(w1.z, w1.w), (uint32_t)(x0 & 63), c0, c1);
+        const uint32_t ln = p < depth_max ? (uint32_t)p : depth_max;
+        full[kk] = prefix_of(make_ulonglong2(rev_bases(~c0), rev_bases(~c1)), ln);
+        len[kk] = ln;
+        const uint32_t t = (uint32_t)(p % ix.interval);
+        n_ev[kk] = 1;
+        ev0[kk] = ((uint64_t)t << 58) | p;
+      } else {
+        const Block2* b2 = ix.blocks2 + (row >> 6);
+        const uint64_t rows = b2->chain_rows, base = b2->chain_base;
+        const uint32_t o = (uint32_t)(row & 63);
+        if (!((rows >> o) & 1ull)) { fail = true; continue; }
+        const uint4* ce = reinterpret_cast<const uint4*>(ix.chain_tab + base + (uint64_t)__popcll(rows & below(o)));
+        const uint4 q0 = ce[0], q1 = ce[1];
+        full[kk] = make_ulonglong2(u64_of(q0.x, q0.y), u64_of(q0.z, q0.w));
+        meta[kk] = u64_of(q1.x, q1.y);
+        ev0[kk] = u64_of(q1.z, q1.w);
+        n_ev[kk] = (uint32_t)meta[kk] & 0xFFu;
+        len[kk] = (uint32_t)(meta[kk] >> 8) & 0xFFu;
+      }
+      kb[i] = full[kk];
+      len_of[i] = (uint8_t)len[kk];
+    }
+    if (fail) cnt[0] = 1u;
+    team_sync<T>();
+    // ---- a node of one sampled row has no children: an event at depth d >= 1 in a node no other chain passes through
+    // ends its chain (only chains with several events can lose any)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t i = 4u * tid + (uint32_t)kk;
+      if (n_ev[kk] < 2u) continue;
+      const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
+      uint32_t keep = n_ev[kk];
+      for (uint32_t j = 0; j + 1 < n_ev[kk]; ++j) {
+        const uint32_t d = (uint32_t)((j == 0 ? ev0[kk] : evs[j - 1]) >> 58);
+        if (d == 0) continue;  // (level 0, searcher.hpp:424-443, has no early return)
+        const ulonglong2 w = prefix_of(full[kk], d);
+        bool alone = true;
+        for (uint32_t o = 0; o < m && alone; ++o) {
+          if (o == i || len_of[o] < d) continue;
+          const ulonglong2 v = prefix_of(kb[o], d);
+          alone = v.x != w.x || v.y != w.y;
+        }
+        if (alone) { keep = j + 1; break; }
+      }
+      n_ev[kk] = keep;
+    }
+    // ---- entries: numbered thread by thread, i.e. in row order
+    uint32_t H;
+    uint32_t slot = team_excl_scan(n_ev[0] + n_ev[1] + n_ev[2] + n_ev[3], &H);
+    const bool failed = cnt[0] != 0 || H > kCap;  // (team-uniform: cnt[0] was written before the sync above)
+    if (failed) continue;
+    team_sync<T>();  // every thread is done with kb (the sort may take it over) before anything else is written
+    uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
+    uint32_t ort = 0, andt = ~0u;
+    bool wrapped = false;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
+      for (uint32_t j = 0; j < n_ev[kk]; ++j) {
+        const uint64_t ev = j == 0 ? ev0[kk] : evs[j - 1];
+        const uint32_t d = (uint32_t)(ev >> 58);
+        const ulonglong2 key = prefix_of(full[kk], d);
+        sbwt_hit h;
+        uint64_t py = (uint64_t)d << 58;
+        if (push_position_keys(ix, t_chr, t_nk, t_nv, ev & kPosMask, L, a.strand, &h)) {
+          if (h.pos0 > kPosMask) wrapped = true;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
+          py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+        }
+        ka[slot] = key;
+        pay[slot] = py;
+        ++slot;
+        or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y; ort |= d; andt &= d;
+      }
+    }
+    if (wrapped) cnt[0] = 1u;
+    team_sync<T>();
+    const bool failed2 = cnt[0] != 0;
+    team_sync<T>();  // (nobody writes cnt[0] again before every thread has read it)
+    if (failed2) continue;
+    bool radix = false;
+    const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+    // ---- accepted hits before every place, node boundaries, the cut (as k_multi_bfs)
+    uint32_t base = 0;
+    for (uint32_t c = 0; c < H; c += T) {
+      const uint32_t k = c + tid;
+      bool ok = false;
+      if (k < H) ok = (pay[sorted.ord[k] & kOrdMask] & kPayOk) != 0;
+      uint32_t tot;
+      const uint32_t off = base + team_excl_scan(ok ? 1u : 0u, &tot);
+      base += tot;
+      if (k < H) acc_of[k] = (uint16_t)off;  // accepted hits before place k
+    }
+    if (tid == 0) cnt[1] = H;
+    team_sync<T>();
+    const uint64_t maybe = (uint64_t)(int64_t)(int32_t)m;  // (searcher.hpp:412,464: an int against a size_t)
+    for (uint32_t k = tid + 1; k < H; k += T) {
+      const uint32_t ia = sorted.ord[k - 1] & kOrdMask, ib = sorted.ord[k] & kOrdMask;
+      const ulonglong2 qa = sorted_key(sorted, sort_lds, k - 1), qb = sorted_key(sorted, sort_lds, k);
+      const bool boundary = qa.x != qb.x || qa.y != qb.y || (pay[ia] >> 58) != (pay[ib] >> 58);
+      if (boundary && (uint64_t)acc_of[k] == maybe) atomicMin(&cnt[1], k);
+    }
+    team_sync<T>();
+    const uint32_t cut = cnt[1];
+    const uint32_t nres = cut < H ? (uint32_t)acc_of[cut] : base;
+    sbwt_hit* out = a.hits + res.first_hit;
+    for (uint32_t k = tid; k < cut; k += T) {
+      const uint64_t py = pay[sorted.ord[k] & kOrdMask];
+      if ((py & kPayOk) && (uint32_t)acc_of[k] < m) {
+        sbwt_hit h;
+        h.pos0 = py & kPosMask;
+        h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
+        h.is_rc = (uint32_t)(py >> 56) & 1u;
+        out[acc_of[k]] = h;
+      }
+    }
+    if (tid == 0) {
+      rio_store_multi(a.io, r, res.first_hit, true, (int32_t)(nres < m ? nres : m), nres > m ? SBWT_RF_TRUNCATED : 0u);
+      queue[q] = kQueueDone;
+      atomicAdd(chain_count, 1ull);
+    }
+  }
+}
+
 }  // namespace sbwt

@@ -126,23 +126,28 @@ def test_tie_shuffled_index_matches_oracle(golden_dir, oracle, k, seed):
     assert (nh > 0).sum() > len(reads) // 3
     st = ctx.last_stats_ex()
     ctx.close()
-    # the reads whose rows lie in LF-inconsistent regions take upstream's walk: level by level (k_multi_bfs) unless
-    # switched off, then depth first (k_multi) -- the same lists either way
+    # the reads whose rows lie in LF-inconsistent regions: their lists are put together from the memoised chains of their
+    # rows (k_multi_chain); without chain_tab they take upstream's walk level by level (k_multi_bfs), without that depth
+    # first (k_multi) -- the same lists every way
     if k < 1000:
-        assert st[3] > 0 and st[9] == st[3]
-        os.environ["SBWT_NO_BFS"] = "1"
-        try:
-            ctx = sb.Context(ix, len(reads))
-            res2, hits2 = ctx.map_batch(packed, lens)
-            st2 = ctx.last_stats_ex()
-            ctx.close()
-        finally:
-            os.environ.pop("SBWT_NO_BFS")
-        assert st2[3] == st[3] and st2[9] == 0
-        np.testing.assert_array_equal(res2["nh"], nh)
-        for r in np.nonzero(nh)[0]:
-            a = hits2[int(res2["first_hit"][r]): int(res2["first_hit"][r]) + int(nh[r])]
-            assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d (depth first)" % r
+        assert ix.info().n > 0 and st[3] > 0 and st[11] + st[9] == st[3] and st[11] > 0
+        for knobs, want in ((("SBWT_NO_CHAIN",), "bfs"), (("SBWT_NO_CHAIN", "SBWT_NO_BFS"), "dfs")):
+            for kn in knobs:
+                os.environ[kn] = "1"
+            try:
+                ctx = sb.Context(ix, len(reads))
+                res2, hits2 = ctx.map_batch(packed, lens)
+                st2 = ctx.last_stats_ex()
+                ctx.close()
+            finally:
+                for kn in knobs:
+                    os.environ.pop(kn)
+            assert st2[3] == st[3] and st2[11] == 0 and (st2[9] == st[3] if want == "bfs" else st2[9] == 0)
+            np.testing.assert_array_equal(res2["nh"], nh)
+            np.testing.assert_array_equal(res2["flags"], res["flags"])
+            for r in np.nonzero(nh)[0]:
+                a = hits2[int(res2["first_hit"][r]): int(res2["first_hit"][r]) + int(nh[r])]
+                assert np.array_equal(a, ohits[int(first[r]): int(first[r]) + int(nh[r])]), "read %d (%s)" % (r, want)
     ix.close(); oix.close()
 
 
