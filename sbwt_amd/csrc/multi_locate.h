@@ -228,64 +228,70 @@ __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, uint32_t lane_mask) {
 // pos0 (40 bits) | chr_id << 40 (16 bits) | is_rc << 56 | passed the filters << 57 | t << 58 (6 bits)
 constexpr uint64_t kPayOk = 1ull << 57;
 
-// What the sort of one read's entries works on (LDS of the team).  An entry is one reported hit of the read: the bases
-// its node prepended (ka[i].x | ka[i].y: first base most significant, zero padded) and pay[i] (depth t in the top six bits).
+// What the sort of one read's entries works on (LDS of the team).  An entry is one reported hit of the read; its sort key
+// is 16 bytes (sort_key below): the bases its node prepended and its depth.
 struct SortLds {
-  ulonglong2 *ka, *kb;  // the full keys; a second buffer of the same size (merge passes; the radix path's counters)
-  uint16_t *ta, *tb;    // t << 10 | entry index: the tail of the sort key, and what the sort returns in order
-  uint64_t* pay;
-  uint64_t (*red)[5];
+  ulonglong2 *ka, *kb;  // the keys of entries 0 .. m-1; a second buffer of the same size (merge passes; the radix path's counters)
+  uint16_t *ta, *tb;    // entry indices in order so far, ping-pong
+  uint64_t (*red)[4];
   uint32_t* scan;
 };
-constexpr uint32_t kOrdMask = 1023u;  // entry index of an element of the returned order
+// The emission order of two hits: the strings their nodes prepended, zero padded (a string before its extensions,
+// A < C < G < T), then the depth t, then -- hits of ONE node -- row order.  (h0, h1) = the up to 63 prepended bases, first
+// base most significant, zero beyond t; t <= 63.  The key is (x, y) compared as one 128-bit number: x = bases 0..31,
+// y = bases 32..59 over an 8-bit code that orders (bases 60..62, t) the same way -- t itself when t <= 60, else the
+// pre-order number of the node below depth 60 (a 4-ary trie of depth 3: 21 nodes under every first base, 5 under every
+// second).  One 16-byte LDS read per comparison, and no tie-break in the key: the sort is stable and entries are
+// numbered in row order.
+__device__ __forceinline__ ulonglong2 sort_key(uint64_t h0, uint64_t h1, uint32_t t) {
+  uint32_t code = t;
+  if (t > 60u) {
+    const uint32_t c60 = (uint32_t)(h1 >> 6) & 3u, c61 = (uint32_t)(h1 >> 4) & 3u, c62 = (uint32_t)(h1 >> 2) & 3u;
+    code = 61u + c60 * 21u + (t >= 62u ? 1u + c61 * 5u + (t >= 63u ? 1u + c62 : 0u) : 0u);
+  }
+  return make_ulonglong2(h0, (h1 & ~0xFFull) | code);
+}
 struct SortedRows {
-  const uint16_t* ord;     // entry at place k = ord[k] & kOrdMask
-  const ulonglong2* keys;  // its full key = keys[k]; null: ka[ord[k] & kOrdMask] (the merge passes move the keys, the radix passes do not)
+  const uint16_t* ord;     // entry at place k = ord[k]
+  const ulonglong2* keys;  // its key = keys[k]; null: ka[ord[k]] (the merge passes move the keys, the radix passes do not)
 };
 __device__ __forceinline__ ulonglong2 sorted_key(const SortedRows& R, const SortLds& S, uint32_t k) {
-  return R.keys ? R.keys[k] : S.ka[R.ord[k] & kOrdMask];
+  return R.keys ? R.keys[k] : S.ka[R.ord[k]];
 }
 
-// Puts the m entries of one read in emission order: full key (ka.x, ka.y, t) ascending, ties in entry order (the entries
-// of one node are numbered in row order).  or0 .. andt: OR and AND of the key words over the calling thread's entries.
-// Returns the order (SortedRows); ka and kb do not keep their contents.  Every thread of the team calls it.
+// Puts the m entries of one read in emission order: keys ascending, equal keys in entry order.  or0 .. and1: OR and AND
+// of the key words over the calling thread's entries.  Returns the order (SortedRows); ka and kb do not keep their
+// contents.  Every thread of the team calls it.
 //
 // Two ways.  (1) Few 8-bit digits of the key differ between the entries (copies of a repeat share most of their left
 // context): one stable counting pass per differing digit.  (2) Otherwise a merge sort whose merges are done by RANK:
 // every element of two sorted runs finds its place in the merged run by a binary search over the other run -- log2(run)
-// + 1 dependent LDS reads, four independent searches per thread in flight, ONE synchronisation per level and no
+// + 1 dependent 16-byte LDS reads, four independent searches per thread in flight, ONE synchronisation per level and no
 // data-dependent branch.  (The bitonic network this replaces made log^2 passes of compare-EXCHANGES, each a dependent
 // read-compare-write round trip through LDS with a second round trip for entries whose first 24 bases tie -- diverged
-// repeat copies tie all the time: 1,800 clocks per pass, 58-77 % of k_multi_sort on a repeat-rich genome.)
+// repeat copies tie all the time.)
 template <int T>
 __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t m, uint32_t tid, uint32_t lane,
-                                                          uint64_t or0, uint64_t and0, uint64_t or1, uint64_t and1, uint32_t ort,
-                                                          uint32_t andt, bool& used_radix) {
+                                                     uint64_t or0, uint64_t and0, uint64_t or1, uint64_t and1, bool& used_radix) {
   constexpr uint32_t kCap = kSortMax / (256 / T);
   constexpr uint32_t kWaveRows = kCap / 64;  // 64-entry groups of a team's entries: the unit the radix passes rank in
   ulonglong2* const ka = S.ka;
-  uint64_t* const pay = S.pay;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
-  // Which 8-bit digits of the full key -- k0 | k1 | t, 17 digits -- differ between the entries of this read?  The
-  // emission order is the order of the full keys with ties in entry order, i.e. what a STABLE sort by those digits
-  // alone gives.
+  // Which 8-bit digits of the key differ between the entries of this read?  The emission order is what a STABLE sort by
+  // those digits alone gives.
   bool radix;
-  uint32_t dmask = 0;  // bit d: digit d differs (0 = the first four bases ... 15 = bases 60..63, 16 = t)
+  uint32_t dmask = 0;  // bit d: digit d differs (0 = the first four bases ... 15 = the code)
   {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
       or0 |= shfl_xor64(or0, (uint32_t)d); and0 &= shfl_xor64(and0, (uint32_t)d);
       or1 |= shfl_xor64(or1, (uint32_t)d); and1 &= shfl_xor64(and1, (uint32_t)d);
-      ort |= (uint32_t)__shfl_xor((int)ort, d); andt &= (uint32_t)__shfl_xor((int)andt, d);
     }
     if (T == 256) {
       uint64_t* red = S.red[threadIdx.x >> 6];
-      if (lane == 0) { red[0] = or0; red[1] = and0; red[2] = or1; red[3] = and1; red[4] = u64_of(ort, andt); }
+      if (lane == 0) { red[0] = or0; red[1] = and0; red[2] = or1; red[3] = and1; }
       __syncthreads();
-      for (uint32_t v = 0; v < 4; ++v) {
-        or0 |= S.red[v][0]; and0 &= S.red[v][1]; or1 |= S.red[v][2]; and1 &= S.red[v][3];
-        ort |= (uint32_t)S.red[v][4]; andt &= (uint32_t)(S.red[v][4] >> 32);
-      }
+      for (uint32_t v = 0; v < 4; ++v) { or0 |= S.red[v][0]; and0 &= S.red[v][1]; or1 |= S.red[v][2]; and1 &= S.red[v][3]; }
     }
     const uint64_t v0 = or0 & ~and0, v1 = or1 & ~and1;
 #pragma unroll
@@ -293,18 +299,17 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
       if ((v0 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << b;
       if ((v1 >> (56 - 8 * b)) & 0xFFull) dmask |= 1u << (8 + b);
     }
-    if (ort & ~andt) dmask |= 1u << 16;
     dmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)dmask);
     radix = __popc(dmask) <= (int)kRadixMaxPasses;
   }
   used_radix = radix;
+  uint16_t* ts = S.ta;
+  uint16_t* td = S.tb;
+  for (uint32_t k = tid; k < m; k += T) ts[k] = (uint16_t)k;
+  team_sync<T>();
   if (radix) {
-    uint16_t* oin = S.ta;
-    uint16_t* oout = S.tb;
-    for (uint32_t k = tid; k < m; k += T) oin[k] = (uint16_t)k;
-    team_sync<T>();
     uint16_t* const h16 = reinterpret_cast<uint16_t*>(S.kb);  // [256 digits][kWaveRows] counters
-    for (int d = 16; d >= 0; --d) {
+    for (int d = 15; d >= 0; --d) {
       if (!((dmask >> d) & 1u)) continue;
       for (uint32_t k = tid; k < kCap * 2u; k += T) reinterpret_cast<uint32_t*>(S.kb)[k] = 0u;
       team_sync<T>();
@@ -316,9 +321,8 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
         if (wr * 64u >= m) continue;  // wave-uniform
         const bool valid = j < m;
         if (valid) {
-          idx[kk] = oin[j];
-          dig[kk] = d == 16 ? (uint32_t)(pay[idx[kk]] >> 58)
-                            : (uint32_t)((d >= 8 ? ka[idx[kk]].y : ka[idx[kk]].x) >> (56 - 8 * (d & 7))) & 0xFFu;
+          idx[kk] = ts[j];
+          dig[kk] = (uint32_t)((d >= 8 ? ka[idx[kk]].y : ka[idx[kk]].x) >> (56 - 8 * (d & 7))) & 0xFFu;
         }
         // lanes of this 64-entry group with the same digit; an entry's place among them
         uint64_t peers = __ballot(valid);
@@ -365,28 +369,22 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const uint32_t j = tid + (uint32_t)kk * T, wr = j >> 6;
-        if (j < m) oout[(uint32_t)h16[dig[kk] * kWaveRows + wr] + rnk[kk]] = (uint16_t)idx[kk];
+        if (j < m) td[(uint32_t)h16[dig[kk] * kWaveRows + wr] + rnk[kk]] = (uint16_t)idx[kk];
       }
       team_sync<T>();
-      uint16_t* const sw = oin; oin = oout; oout = sw;
+      uint16_t* const sw = ts; ts = td; td = sw;
     }
-    return SortedRows{oin, nullptr};
+    return SortedRows{ts, nullptr};
   }
   // ---- merge sort by rank
   const ulonglong2* src = S.ka;
   ulonglong2* dst = S.kb;
-  uint16_t* ts = S.ta;
-  uint16_t* td = S.tb;
-  for (uint32_t k = tid; k < m; k += T) ts[k] = (uint16_t)(((uint32_t)(pay[k] >> 58) << 10) | k);
-  team_sync<T>();
-  auto elem_less = [](const ulonglong2& a, uint32_t at, const ulonglong2& b, uint32_t bt) -> bool {
-    return a.x < b.x || (a.x == b.x && (a.y < b.y || (a.y == b.y && at < bt)));
-  };
+  auto key_less = [](const ulonglong2& a, const ulonglong2& b) -> bool { return a.x < b.x || (a.x == b.x && a.y < b.y); };
   {
     // Entries whose left contexts agree over their whole length (copies of a repeat at the same phase of the sampling,
     // say) are in emission order as they stand: one pass finds out
     bool in_order = true;
-    for (uint32_t i = tid; i + 1 < m; i += T) in_order = in_order && elem_less(src[i], ts[i], src[i + 1], ts[i + 1]);
+    for (uint32_t i = tid; i + 1 < m; i += T) in_order = in_order && !key_less(src[i + 1], src[i]);
     const bool wave_ok = __all(in_order);
     if (T == 256) {
       if (lane == 0) S.scan[threadIdx.x >> 6] = wave_ok ? 1u : 0u;
@@ -401,30 +399,32 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
   for (uint32_t R = 1; R < m; R <<= 1) {  // sorted runs of R elements -> of 2R
     ulonglong2 e[4];
     uint32_t et[4], ob[4], olen[4], cnt[4], dbase[4];
+    bool right[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint32_t x = tid + (uint32_t)kk * T;
-      ob[kk] = 0; olen[kk] = 0; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0;
+      ob[kk] = 0; olen[kk] = 0; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0; right[kk] = false;
       e[kk] = make_ulonglong2(0, 0);
       if (x < m) {
         e[kk] = src[x];
         et[kk] = ts[x];
         const uint32_t pair_base = x & ~(2u * R - 1u);
-        const uint32_t other = pair_base + ((x & R) ? 0u : R);  // the run this element is merged with
+        right[kk] = (x & R) != 0;
+        const uint32_t other = pair_base + (right[kk] ? 0u : R);  // the run this element is merged with
         dbase[kk] = pair_base + (x & (R - 1u));
         if (other < m) { ob[kk] = other; olen[kk] = m - other < R ? m - other : R; }
       }
     }
-    // elements of the other run below this one (keys are distinct: the entry index is part of them), by binary lifting
+    // elements of the other run that go before this one, by binary lifting: those below it, and -- stability -- for an
+    // element of the right run those equal to it too
     for (uint32_t step = R; step; step >>= 1) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const uint32_t c = cnt[kk] + step;
         const bool in = c <= olen[kk];
-        const uint32_t o = ob[kk] + (in ? c - 1u : 0u);
-        const ulonglong2 v = src[o];
-        const uint32_t vt = ts[o];
-        if (in && elem_less(v, vt, e[kk], et[kk])) cnt[kk] = c;
+        const ulonglong2 v = src[ob[kk] + (in ? c - 1u : 0u)];
+        const bool before = right[kk] ? !key_less(e[kk], v) : key_less(v, e[kk]);
+        if (in && before) cnt[kk] = c;
       }
     }
 #pragma unroll
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
   constexpr uint32_t kFrontierBytes = 2u * 3u * kNodes * 8u, kSortBytes = kCap * (16u + 4u * 2u);
   constexpr uint32_t kRawTeam = kFrontierBytes > kSortBytes ? kFrontierBytes : kSortBytes;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTeams * kRawTeam];
-  __shared__ uint64_t s_red_all[4][5];
+  __shared__ uint64_t s_red_all[4][4];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_cnt_all[kTeams][4];  // hits, nodes of the next level, overflow, cut
   // workgroup teams: children of more than kBigRows rows are scanned by a whole wave (a lane per 64-row block), not by
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
   uint16_t* acc_of = ord0 + 3u * kCap;
   uint32_t* cnt = s_cnt_all[team];
   uint8_t* const pruned = s_pruned_all[team];
-  const SortLds sort_lds{ka, reinterpret_cast<ulonglong2*>(raw), ord0, ord0 + kCap, pay, s_red_all, s_scan_all};
+  const SortLds sort_lds{ka, reinterpret_cast<ulonglong2*>(raw), ord0, ord0 + kCap, s_red_all, s_scan_all};
   if (ix.interval > 64 || ix.n_chr > 0xFFFFu) return;  // key / payload fields too narrow: k_multi
   const uint64_t qn = *queue_count;
 #ifdef SBWT_PHASE_CLOCKS
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
           if (h.pos0 > kPosMask) cnt[2] = 1u;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
           py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
         }
-        ka[at] = make_ulonglong2(p0, p1); pay[at] = py;
+        ka[at] = sort_key(p0, p1, depth); pay[at] = py;
         ++at;
       }
     }
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
                 if (h.pos0 > kPosMask) cnt[2] = 1u;
                 py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
               }
-              ka[at] = make_ulonglong2(p0, p1); pay[at] = py;
+              ka[at] = sort_key(p0, p1, d); pay[at] = py;
               ++at;
             }
           }
@@ -713,15 +713,13 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     const uint32_t H = cnt[0];
     // ---- emission order
     uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
-    uint32_t ort = 0, andt = ~0u;
     for (uint32_t i = tid; i < H; i += T) {
       const ulonglong2 h = ka[i];
-      const uint32_t t = (uint32_t)(pay[i] >> 58);
-      or0 |= h.x; and0 &= h.x; or1 |= h.y; and1 &= h.y; ort |= t; andt &= t;
+      or0 |= h.x; and0 &= h.x; or1 |= h.y; and1 &= h.y;
     }
     team_sync<T>();  // (the frontiers in the team's region are dead: the sort takes it over)
     bool radix = false;
-    const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+    const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, radix);
     SBWT_PHASE(4);
     // ---- accepted hits before every place, node boundaries, the cut
     uint32_t base = 0;
@@ -730,7 +728,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
       uint32_t i = 0;
       bool ok = false;
       if (k < H) {
-        i = sorted.ord[k] & kOrdMask;
+        i = sorted.ord[k];
         ok = (pay[i] & kPayOk) != 0;
         idx_of[k] = (uint16_t)i;
       }
@@ -752,9 +750,8 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     team_sync<T>();
     const uint64_t maybe = (uint64_t)(int64_t)(int32_t)(uint32_t)m;  // (searcher.hpp:412,464: an int against a size_t)
     for (uint32_t k = tid + 1; k < H; k += T) {
-      const uint32_t ia = idx_of[k - 1], ib = idx_of[k];
       const ulonglong2 qa = sorted_key(sorted, sort_lds, k - 1), qb = sorted_key(sorted, sort_lds, k);
-      const bool boundary = qa.x != qb.x || qa.y != qb.y || (pay[ia] >> 58) != (pay[ib] >> 58);
+      const bool boundary = qa.x != qb.x || qa.y != qb.y;  // (the depth is part of the key)
       if (boundary && (uint64_t)acc_of[k] == maybe) atomicMin(&cnt[3], k);
     }
     team_sync<T>();
@@ -800,7 +797,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_bad_all[4];
   __shared__ uint16_t s_ord_all[2][kSortMax];
-  __shared__ uint64_t s_red_all[4][5];          // OR / AND of the key words over a wave's rows
+  __shared__ uint64_t s_red_all[4][4];          // OR / AND of the key words over a wave's rows
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];  // (n_chr + 2 n_npos) words when a.lds_tables
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
   // push_position tables: LDS copies when they fit
@@ -826,7 +823,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   uint64_t* pay = s_pay + team * kCap;
   uint32_t* list = s_list_all + team * T;
   uint32_t* s_bad = s_bad_all + team;
-  const SortLds sort_lds{ka, s_kb + team * kCap, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, pay, s_red_all, s_scan_all};
+  const SortLds sort_lds{ka, s_kb + team * kCap, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, s_red_all, s_scan_all};
   const uint64_t m_text = ix.n - 1;
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
   // teams stride over the waves of the search kernel; each wave queued its reads at queue[w * chunk ..)
@@ -871,7 +868,6 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
         team_sync<T>();
         SBWT_PHASE_MEM(1);
         uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;  // over this thread's rows: which key bits differ
-        uint32_t ort = 0, andt = ~0u;
         if (!*s_bad) {
           // up to four rows per thread, phase by phase, so that the loads of all of them are in flight together
           uint64_t e4[4];
@@ -929,7 +925,8 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint32_t i = tid + (uint32_t)kk * T;
-            uint64_t h0 = ~0ull, h1 = ~0ull, py = 63ull << 58;
+            ulonglong2 key = make_ulonglong2(~0ull, ~0ull);
+            uint64_t py = 63ull << 58;
             if (i < m) {
               const uint64_t e = e4[kk];
               const uint64_t p = e & kPosMask;
@@ -946,15 +943,14 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
                 cc1 = ~cc1;
                 if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; cc1 = 0; }
                 else if (t < 64u) cc1 &= t > 32u ? ((1ull << (2 * (t - 32u))) - 1ull) : 0ull;
-                h0 = rev_bases(c0);
-                h1 = rev_bases(cc1);
+                key = sort_key(rev_bases(c0), rev_bases(cc1), t);
                 py = ((uint64_t)t << 58);
                 if (ok && h.pos0 > kPosMask) *s_bad = 1u;  // (an upstream-accepted wrapped position: the depth-first kernel writes whole hits)
                 if (ok) py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
-                or0 |= h0; and0 &= h0; or1 |= h1; and1 &= h1; ort |= t; andt &= t;
+                or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y;
               }
             }
-            if (i < m) { ka[i] = make_ulonglong2(h0, h1); pay[i] = py; }
+            if (i < m) { ka[i] = key; pay[i] = py; }
           }
         }
         team_sync<T>();
@@ -968,7 +964,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
           continue;
         }
         bool radix = false;
-        const SortedRows sorted = team_sort_rows<T>(sort_lds, (uint32_t)m, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+        const SortedRows sorted = team_sort_rows<T>(sort_lds, (uint32_t)m, tid, lane, or0, and0, or1, and1, radix);
         SBWT_PHASE(6);
         // rows in emission order: compact those that passed the filters, write
         sbwt_hit* out = a.hits + res.first_hit;
@@ -976,7 +972,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
         for (uint32_t c = 0; c < m; c += T) {
           const uint32_t k = c + tid;
           uint64_t py = 0;
-          if (k < m) py = pay[sorted.ord[k] & kOrdMask];
+          if (k < m) py = pay[sorted.ord[k]];
           const bool ok = (py & kPayOk) != 0;
           sbwt_hit h;
           h.pos0 = py & kPosMask;
@@ -1039,7 +1035,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
   __shared__ uint16_t s_ord_all[2][kSortMax];
   __shared__ uint16_t s_acc_all[kSortMax];
   __shared__ uint8_t s_len_all[kSortMax];
-  __shared__ uint64_t s_red_all[4][5];
+  __shared__ uint64_t s_red_all[4][4];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_cnt_all[kTeams][4];  // [0] fail, [1] cut
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
@@ -1062,7 +1058,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
   uint16_t* const acc_of = s_acc_all + team * kCap;
   uint8_t* const len_of = s_len_all + team * kCap;
   uint32_t* const cnt = s_cnt_all[team];
-  const SortLds sort_lds{ka, kb, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, pay, s_red_all, s_scan_all};
+  const SortLds sort_lds{ka, kb, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, s_red_all, s_scan_all};
   const uint64_t qn = *queue_count;
   const uint64_t m_text = ix.n - 1;
   const uint32_t depth_max = (uint32_t)ix.interval - 1u;  // bases a chain can hold
@@ -1180,7 +1176,6 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     if (failed) continue;
     team_sync<T>();  // every thread is done with kb (the sort may take it over) before anything else is written
     uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
-    uint32_t ort = 0, andt = ~0u;
     bool wrapped = false;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -1188,7 +1183,8 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
       for (uint32_t j = 0; j < n_ev[kk]; ++j) {
         const uint64_t ev = j == 0 ? ev0[kk] : evs[j - 1];
         const uint32_t d = (uint32_t)(ev >> 58);
-        const ulonglong2 key = prefix_of(full[kk], d);
+        const ulonglong2 pre = prefix_of(full[kk], d);
+        const ulonglong2 key = sort_key(pre.x, pre.y, d);
         sbwt_hit h;
         uint64_t py = (uint64_t)d << 58;
         if (push_position_keys(ix, t_chr, t_nk, t_nv, ev & kPosMask, L, a.strand, &h)) {
@@ -1198,7 +1194,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
         ka[slot] = key;
         pay[slot] = py;
         ++slot;
-        or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y; ort |= d; andt &= d;
+        or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y;
       }
     }
     if (wrapped) cnt[0] = 1u;
@@ -1207,13 +1203,13 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     team_sync<T>();  // (nobody writes cnt[0] again before every thread has read it)
     if (failed2) continue;
     bool radix = false;
-    const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, ort, andt, radix);
+    const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, radix);
     // ---- accepted hits before every place, node boundaries, the cut (as k_multi_bfs)
     uint32_t base = 0;
     for (uint32_t c = 0; c < H; c += T) {
       const uint32_t k = c + tid;
       bool ok = false;
-      if (k < H) ok = (pay[sorted.ord[k] & kOrdMask] & kPayOk) != 0;
+      if (k < H) ok = (pay[sorted.ord[k]] & kPayOk) != 0;
       uint32_t tot;
       const uint32_t off = base + team_excl_scan(ok ? 1u : 0u, &tot);
       base += tot;
@@ -1223,9 +1219,8 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     team_sync<T>();
     const uint64_t maybe = (uint64_t)(int64_t)(int32_t)m;  // (searcher.hpp:412,464: an int against a size_t)
     for (uint32_t k = tid + 1; k < H; k += T) {
-      const uint32_t ia = sorted.ord[k - 1] & kOrdMask, ib = sorted.ord[k] & kOrdMask;
       const ulonglong2 qa = sorted_key(sorted, sort_lds, k - 1), qb = sorted_key(sorted, sort_lds, k);
-      const bool boundary = qa.x != qb.x || qa.y != qb.y || (pay[ia] >> 58) != (pay[ib] >> 58);
+      const bool boundary = qa.x != qb.x || qa.y != qb.y;  // (the depth is part of the key)
       if (boundary && (uint64_t)acc_of[k] == maybe) atomicMin(&cnt[1], k);
     }
     team_sync<T>();
@@ -1233,7 +1228,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     const uint32_t nres = cut < H ? (uint32_t)acc_of[cut] : base;
     sbwt_hit* out = a.hits + res.first_hit;
     for (uint32_t k = tid; k < cut; k += T) {
-      const uint64_t py = pay[sorted.ord[k] & kOrdMask];
+      const uint64_t py = pay[sorted.ord[k]];
       if ((py & kPayOk) && (uint32_t)acc_of[k] < m) {
         sbwt_hit h;
         h.pos0 = py & kPosMask;
