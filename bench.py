@@ -566,9 +566,11 @@ class Run:
         if A["multi_ms"] > A["kernel_ms"]:
             # locate-bound workloads: the multi-hit kernels take most of the step; one text (or chain) line + the sa_full
             # word in and a 16-byte hit out per raw row, the search kernel's lines on top
-            A["kernel"], A["kernel_ms"] = "multi-hit locate (k_multi_sort / k_multi_bfs)", A["multi_ms"]
-            A["accesses"] = int(self.list_hits)
-            A["streamed"] = int(self.list_hits) * (8 + 16)
+            rows = int(stats[12]) if len(stats) > 12 else int(self.list_hits)   # raw rows located (a list several reads share: once)
+            A["kernel"], A["kernel_ms"] = "multi-hit locate (k_multi_sort / k_multi_chain)", A["multi_ms"]
+            A["accesses"] = rows
+            A["streamed"] = rows * (8 + 16)
+            A["rows_located"] = rows
         A["out_bytes"] = out_bytes
         A["algo_bytes"] = 128 * A["accesses"] + A["streamed"]
         A["achieved_GBps"] = A["algo_bytes"] / (A["kernel_ms"] * 1e-3) / 1e9
@@ -587,7 +589,8 @@ class Run:
                 "achieved_GBps": round(A["achieved_GBps"], 1), "frac": round(A["achieved_GBps"] / 8000.0, 4),
                 "hash_hit_rate": round(st[5] / st[4], 4) if st[4] else None,
                 "mapped_reads": self.mapped, "multi_hit_reads": self.multi, "list_hits": int(self.list_hits),
-                "multi_locate_ms": round(A["multi_ms"], 3), "reads_located_by_walk": int(st[3]),
+                "multi_locate_ms": round(A["multi_ms"], 3), "rows_located": int(st[12]) if len(st) > 12 else None,
+                "reads_off_the_text": int(st[3]), "of_which_from_chain_tab": int(st[11]) if len(st) > 11 else 0,
                 "parity_vs_oracle": parity["identical"] if parity else None,
                 "reads_checked": parity["reads_checked"] if parity else 0}
 

@@ -44,6 +44,7 @@ struct Counters {
   unsigned long long bfs_count;       // reads of the depth-first queue located level by level (k_multi_bfs); the rest took k_multi
   unsigned long long absent_count;    // reads the fast pass settled because their prefix occurs nowhere (DeviceIndex::hash_complete)
   unsigned long long chain_count;     // reads of the depth-first queue located from memoised chains (k_multi_chain)
+  unsigned long long rows_located;    // raw rows of the multi-hit reads that were located themselves (leaders; a shared list counts once)
 };
 
 struct MapArgs {
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
       }
     }
     rio_store_multi(a.io, r, res.first_hit, true, (int32_t)(S.nres < S.cap ? S.nres : S.cap), S.truncated ? SBWT_RF_TRUNCATED : 0u);
+    atomicAdd(&a.ctr->rows_located, (unsigned long long)(hi - lo));  // (the few reads nothing else took)
   }
 }
 
@@ -166,7 +168,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 12;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 13;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -205,7 +207,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -233,7 +235,7 @@ static hipError_t plan_launches(const sbwt_index* ix, MapWork* w) {
   hipError_t e = hipGetDeviceProperties(&prop, ix->device);
   if (e != hipSuccess) return e;
   const uint64_t n_super = ((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1;
-  const size_t ring_bytes = (size_t)4 * kSmRing * 16;  // four waves per workgroup
+  const size_t ring_bytes = (size_t)4 * (kSmRing + kSmStage) * 16;  // four waves per workgroup: the result ring and the stage of the Block2 lines
   w->sm_ring_bytes = ring_bytes;
   w->sm_lds_bytes = 0;
   w->sort_lds_bytes = 0;
@@ -508,6 +510,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     ms.lds_tables = w.sort_lds_bytes ? 1u : 0u;
     ms.shared_count = &w.d_ctr->shared_count;
     ms.bfs_count = &w.d_ctr->bfs_count;
+    ms.rows_count = &w.d_ctr->rows_located;
     ms.grp.keys = nullptr;
     ms.grp.leader = nullptr;
     ms.grp.mask = 0;
@@ -589,6 +592,7 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     stats_out[8] = (accumulate ? stats_out[8] : 0) + w.h_ctr->shared_count;
     stats_out[9] = (accumulate ? stats_out[9] : 0) + w.h_ctr->bfs_count;
     stats_out[11] = (accumulate ? stats_out[11] : 0) + w.h_ctr->chain_count;
+    stats_out[12] = (accumulate ? stats_out[12] : 0) + w.h_ctr->rows_located;
   }
   *multi_used = w.h_ctr->hit_count;
   if (wide_used) *wide_used = w.h_ctr->wide_count;
@@ -705,7 +709,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     SBWT_LAUNCHED();
     const ResultIO io2 = plain ? ResultIO{c->d_pend_res, nullptr, nullptr, 0, c->d_pend_hits} : ResultIO{nullptr, c->d_pend_out, io.wide, io.wide_cap};
     float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
@@ -720,13 +724,13 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent, st[11]};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent, st[11], st[12]};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent, 0};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent, 0, 0};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }

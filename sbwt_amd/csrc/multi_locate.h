@@ -25,7 +25,10 @@
 namespace sbwt {
 
 constexpr uint32_t kSortMax = 1024;
-constexpr uint32_t kRadixMaxPasses = 8;  // differing key digits up to which the stable radix passes beat the comparison sort
+#ifndef SBWT_RADIX_MAX
+#define SBWT_RADIX_MAX 8
+#endif
+constexpr uint32_t kRadixMaxPasses = SBWT_RADIX_MAX;  // differing key digits up to which the stable radix passes beat the comparison sort
 
 // Reads with the same interval and length have the same hit list (the list is a function of the rows, the read
 // length, the strand option and the limit): small-RNA batches hold the same molecule many times over.  The queued
@@ -92,6 +95,7 @@ struct MultiSortArgs {
   GroupArgs grp;
   unsigned long long* shared_count;      // reads whose record points at their leader's list (k_multi_share)
   unsigned long long* bfs_count;         // reads of the depth-first queue that k_multi_bfs located
+  unsigned long long* rows_count;        // raw rows of the reads the locate kernels located themselves (measurement: a shared list counts once)
 };
 
 // Turns the per-wave totals of k_search_sm into global offsets: exclusive prefix sums of the hit slots and of the
@@ -269,7 +273,9 @@ __device__ __forceinline__ ulonglong2 sorted_key(const SortedRows& R, const Sort
 // + 1 dependent 16-byte LDS reads, four independent searches per thread in flight, ONE synchronisation per level and no
 // data-dependent branch.  (The bitonic network this replaces made log^2 passes of compare-EXCHANGES, each a dependent
 // read-compare-write round trip through LDS with a second round trip for entries whose first 24 bases tie -- diverged
-// repeat copies tie all the time.)
+// repeat copies tie all the time.  Tried beside it, measured on the repeat-rich genome: merges along the merge path, eight
+// places per thread after runs of eight sorted in registers -- a third of the LDS reads, but half the threads idle and a
+// chain of dependent reads per level: k_multi_sort 39 ms against 26.5.)
 template <int T>
 __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t m, uint32_t tid, uint32_t lane,
                                                      uint64_t or0, uint64_t and0, uint64_t or1, uint64_t and1, bool& used_radix) {
@@ -772,6 +778,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
       rio_store_multi(a.io, r, res.first_hit, true, (int32_t)((uint64_t)nres < m ? nres : (uint32_t)m), (uint64_t)nres > m ? SBWT_RF_TRUNCATED : 0u);
       queue[q] = kQueueDone;
       atomicAdd(a.bfs_count, 1ull);
+      atomicAdd(a.rows_count, (unsigned long long)m);
     }
     SBWT_PHASE(5);
 #ifdef SBWT_PHASE_CLOCKS
@@ -826,6 +833,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   const SortLds sort_lds{ka, s_kb + team * kCap, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, s_red_all, s_scan_all};
   const uint64_t m_text = ix.n - 1;
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
+  unsigned long long rows_done = 0;  // (thread 0 of a team)
   // teams stride over the waves of the search kernel; each wave queued its reads at queue[w * chunk ..)
   for (uint32_t w = blockIdx.x * kTeams + team; w < a.n_waves; w += gridDim.x * kTeams) {
     const WaveInfo wi = a.wave_info[w];
@@ -864,20 +872,28 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
         const uint64_t lo = res.lo, m = res.hi - res.lo;
         const uint32_t L = a.lens[r];
         res.first_hit += a.multi_base + wi.slots;  // wave-relative until now
-        if (tid == 0) *s_bad = (m > kCap || no_sort_path) ? 1u : 0u;
+        const bool pre_bad = m > kCap || no_sort_path;  // (team-uniform, from registers)
+        if (tid == 0) *s_bad = pre_bad ? 1u : 0u;
         team_sync<T>();
         SBWT_PHASE_MEM(1);
         uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;  // over this thread's rows: which key bits differ
-        if (!*s_bad) {
+        if (!pre_bad) {
           // up to four rows per thread, phase by phase, so that the loads of all of them are in flight together
           uint64_t e4[4];
           uint4 tw[4][2];  // 32 bytes of textrc from a 16-byte boundary around the row's left context
+          bool row_bad = false;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const uint32_t i = tid + (uint32_t)kk * T;
             e4[kk] = i < m ? ix.sa_full[lo + i] : kNoPosition;
+            const uint64_t p = e4[kk] & kPosMask;
+            if (i < m && (e4[kk] == kNoPosition || (e4[kk] >> kPosBits) < (p + 1 < ix.interval ? p + 1 : ix.interval))) row_bad = true;
           }
+          // a row the text does not answer for: the read goes to k_multi_chain / the walk, and nothing more is fetched for it here
+          if (row_bad) *s_bad = 1u;  // benign race: every writer stores 1
+          team_sync<T>();
           SBWT_PHASE_MEM(2);
+          if (!*s_bad) {  // (wave-uniform: the lanes of a wave read it together; nothing below synchronises the team)
           // ONE load instruction per line (settle.h): the two 16-byte halves of a row's window are fetched by the two
           // lanes of a pair in the same instruction -- round h serves the row of the pair's lane h -- and a DPP swap
           // hands the partner's half over.  (A lane loading both halves itself keeps the second load waiting in the
@@ -952,6 +968,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
             }
             if (i < m) { ka[i] = key; pay[i] = py; }
           }
+          }
         }
         team_sync<T>();
         SBWT_PHASE(4);
@@ -993,7 +1010,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
             base += (uint32_t)__popcll(bal);
           }
         }
-        if (tid == 0) rio_store_multi(a.io, r, res.first_hit, true, (int32_t)base, 0u);
+        if (tid == 0) { rio_store_multi(a.io, r, res.first_hit, true, (int32_t)base, 0u); rows_done += m; }
         team_sync<T>();
         SBWT_PHASE(8);
 #ifdef SBWT_PHASE_CLOCKS
@@ -1002,6 +1019,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
       }
     }
   }
+  if (tid == 0 && rows_done) atomicAdd(a.rows_count, rows_done);
 #ifdef SBWT_PHASE_CLOCKS
   team_sync<T>();
   if (tid < 12 && T == 256) atomicAdd(&g_multi_phase[12 + tid], s_phase[team][tid]);
@@ -1062,6 +1080,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
   const uint64_t qn = *queue_count;
   const uint64_t m_text = ix.n - 1;
   const uint32_t depth_max = (uint32_t)ix.interval - 1u;  // bases a chain can hold
+  unsigned long long rows_done = 0, reads_done = 0;  // (thread 0 of a team; one atomic each when the kernel ends)
   // the first d bases of a chain (d <= 63), zero padded
   auto prefix_of = [](ulonglong2 f, uint32_t d) -> ulonglong2 {
     if (d == 0) return make_ulonglong2(0, 0);
@@ -1159,11 +1178,20 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
         const uint32_t d = (uint32_t)((j == 0 ? ev0[kk] : evs[j - 1]) >> 58);
         if (d == 0) continue;  // (level 0, searcher.hpp:424-443, has no early return)
         const ulonglong2 w = prefix_of(full[kk], d);
+        // (on an index that is k-ordered as far as the walk reaches there IS another chain through the node whenever this one
+        // has a later event -- a lone row would be a unique occurrence from here on -- and it is a row nearby: the copies
+        // the chain hops between share their right contexts too.  So: the neighbours first, and out at the first sharer.)
         bool alone = true;
-        for (uint32_t o = 0; o < m && alone; ++o) {
-          if (o == i || len_of[o] < d) continue;
-          const ulonglong2 v = prefix_of(kb[o], d);
-          alone = v.x != w.x || v.y != w.y;
+        for (uint32_t dl = 1; dl < m && alone; ++dl) {
+          const uint32_t o1 = i + dl;
+          if (o1 < m && len_of[o1] >= d) {
+            const ulonglong2 v = prefix_of(kb[o1], d);
+            alone = v.x != w.x || v.y != w.y;
+          }
+          if (alone && i >= dl && len_of[i - dl] >= d) {
+            const ulonglong2 v = prefix_of(kb[i - dl], d);
+            alone = v.x != w.x || v.y != w.y;
+          }
         }
         if (alone) { keep = j + 1; break; }
       }
@@ -1240,8 +1268,13 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     if (tid == 0) {
       rio_store_multi(a.io, r, res.first_hit, true, (int32_t)(nres < m ? nres : m), nres > m ? SBWT_RF_TRUNCATED : 0u);
       queue[q] = kQueueDone;
-      atomicAdd(chain_count, 1ull);
+      rows_done += m;
+      ++reads_done;
     }
+  }
+  if (tid == 0 && reads_done) {
+    atomicAdd(chain_count, reads_done);
+    atomicAdd(a.rows_count, rows_done);
   }
 }
 

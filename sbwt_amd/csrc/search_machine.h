@@ -171,7 +171,13 @@ struct SmArgs {
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
 constexpr uint32_t kSmMaxSuper = 16;    // superblocks of sb_abs staged in LDS (2^35 suffixes)
-constexpr uint32_t kSmRing = 512;       // results staged per wave (LDS, 16 B each) before they are written as whole lines
+constexpr uint32_t kSmRing = 256;       // results staged per wave (LDS, 16 B each) before they are written as whole lines
+// Block2 lines of the two-base steps arrive through LDS: ONE load instruction per line (settle.h, settle_lookup).  A lane
+// that reads planes and count of its 128-byte line through three loads of its own makes two of them wait in the vector
+// cache behind the first one's miss; instead the four lanes of a quad fetch, in round k, the line of the quad's lane k --
+// lane 0 and 1 its planes, lane 2 the 16 bytes that hold cnt[code] -- as one LDS-DMA instruction (wave base + 16 * lane),
+// and lane k reads its 48 bytes back from LDS.  Per wave: four rounds of 64 slots + one slot of padding a round.
+constexpr uint32_t kSmStageRound = 65, kSmStage = 4 * kSmStageRound;
 // ring entry: word 0 = sa_lo | (sa_hi - sa_lo) << 40 (24 bits), word 1 = payload (40 bits) | chr_id << 40 (16 bits) |
 // meta << 56.  A result that does not fit (interval of 2^24 rows or more, chr_id above 65535) is written to global
 // memory at once and its entry only says so.
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
   // per-wave ring of finished reads (after the tables; 16-byte aligned)
   const uint32_t table_words = kLds ? ((ix.n_chr + 2 * ix.n_npos + 16 * n_super + 1) & ~1u) : 0u;
   uint4* const ring = reinterpret_cast<uint4*>(s_mem + table_words) + (size_t)(threadIdx.x >> 6) * kSmRing;
+  uint4* const s_blk = reinterpret_cast<uint4*>(s_mem + table_words) + 4u * kSmRing + (size_t)(threadIdx.x >> 6) * kSmStage;
   // the wave's contiguous range of reads; lane l owns reads begin + l, begin + l + 64, ...
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -429,6 +436,7 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
     const uint32_t* pd = a.packed;  // 4 B
     bool pair = false;           // S_KMER through the c_functions pair
     bool free_r = true, free_r2 = true;
+    uintptr_t step_line = 0;     // S_STEP_*: the Block2 line of the step
     switch (st) {
       case S_FETCH:
         pr = reinterpret_cast<const uint4*>(rp);
@@ -441,21 +449,17 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
         if (ix.kmer_tab && L >= K) {
           pc = ix.kmer_tab + (cw & kmask);
         } else {
-          pc = ix.c_functions + ((uint32_t)cw & 0xFFFFFFu);
-          pe = pc + 1;
+          // c_functions[kmer], c_functions[kmer + 1]: one 16-byte load (two 8-byte loads of one line would queue behind each other)
+          pa = reinterpret_cast<const uint4_a8*>(ix.c_functions + ((uint32_t)cw & 0xFFFFFFu));
           pair = true;
         }
         break;
       }
       case S_STEP_LO:
-      case S_STEP_HI: {
-        const Block2* b = ix.blocks2 + ((st == S_STEP_LO ? lo : hi) >> 6);
-        pa = reinterpret_cast<const uint4_a8*>(&b->plane[0]);
-        pb = reinterpret_cast<const uint4*>(&b->plane[2]);
-        pd = &b->cnt[aux & 15u];
+      case S_STEP_HI:
+        step_line = reinterpret_cast<uintptr_t>(ix.blocks2 + ((st == S_STEP_LO ? lo : hi) >> 6));  // fetched below, a quad at a time
         tally += 1;
         break;
-      }
       case S_LF1: {
         const Block1* bl = ix.blocks1 + (lo >> 6);
         const Block1* bh = ix.blocks1 + (hi >> 6);
@@ -609,6 +613,24 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
     }
     uint4 vr2 = make_uint4(0, 0, 0, 0);
     if (kLong) vr2 = *pr2;
+    const bool stepping = st == S_STEP_LO || st == S_STEP_HI;
+    if (__any(stepping)) {  // wave-uniform
+      const uint32_t sub = lane & 3u;
+      const uint32_t sl_lo = (uint32_t)step_line, sl_hi = (uint32_t)(step_line >> 32);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t want = quad_bcast(stepping ? 1u : 0u, k);
+        if (!__any(want)) continue;  // wave-uniform
+        const uint32_t code_k = quad_bcast(aux & 15u, k);
+        const uintptr_t q = u64_of(quad_bcast(sl_lo, k), quad_bcast(sl_hi, k)) + (sub < 2u ? 16u * sub : 32u + 16u * (code_k >> 2));
+        if (want && sub < 3u)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
+                                           (__attribute__((address_space(3))) void*)(s_blk + kSmStageRound * k), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
     __builtin_amdgcn_wave_barrier();
 
     if (pf & PF_RW1) {
@@ -692,8 +714,8 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
       }
       case S_KMER: {
         if (pair) {  // init_exact_match, searcher.hpp:83-96
-          lo = vc;
-          hi = ve;
+          lo = u64_of(va.x, va.y);
+          hi = u64_of(va.z, va.w);
         } else {
           apply_prefix(vc, K);
         }
@@ -708,9 +730,14 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
         const bool second = st == S_STEP_HI;
         const uint64_t x = second ? hi : lo;
         const uint64_t blk = x >> 6;
-        const uint64_t q0 = u64_of(va.x, va.y), q1 = u64_of(va.z, va.w), q2 = u64_of(vb.x, vb.y), q3 = u64_of(vb.z, vb.w);
+        // (the stage is read here, in the state that needs it: the values are consumed below, long before the next
+        // iteration's loads can land in it)
+        const uint4* im = s_blk + kSmStageRound * (lane & 3u) + (lane & ~3u);  // round `lane & 3` served this lane
+        const uint4 sb0 = im[0], sb1 = im[1], sb2 = im[2];
+        const uint64_t q0 = u64_of(sb0.x, sb0.y), q1 = u64_of(sb0.z, sb0.w), q2 = u64_of(sb1.x, sb1.y), q3 = u64_of(sb1.z, sb1.w);
         const uint64_t mask = ((code & 1) ? q0 : ~q0) & ((code & 2) ? q1 : ~q1) & ((code & 4) ? q2 : ~q2) & ((code & 8) ? q3 : ~q3);
-        const uint64_t base = T.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code] + vd;
+        const uint32_t cn = (code & 2u) ? ((code & 1u) ? sb2.w : sb2.z) : ((code & 1u) ? sb2.y : sb2.x);  // cnt[code] of the 16 bytes fetched
+        const uint64_t base = T.sb_abs[(blk >> (kSuperShift - 6)) * 16 + code] + cn;
         const uint64_t vx = base + (uint64_t)__popcll(mask & below((uint32_t)(x & 63))) - rank2_correction(ix, code, x);
         bool both = second;
         if (second) {
