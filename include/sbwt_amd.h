@@ -266,7 +266,8 @@ int sbwt_ctx_last_stats(const sbwt_ctx *ctx, uint64_t stats[4]);
  * points at the list of another read of the batch with the same interval and length instead of a list of their own
  * (see first_hit), [9] of the reads in [3], those the level-by-level form of the walk located (k_multi_bfs; [11]: those put
  * together from memoised chains, k_multi_chain; the rest took the depth-first kernel; [12]: raw rows of the multi-hit
- * reads the locate kernels located themselves, a list shared by several reads counted once), [10] reads
+ * reads the locate kernels located themselves, a list shared by several reads counted once; [13]: sub-batches whose
+ * pending pass was launched without waiting for the fast pass), [10] reads
  * the fast pass settled as mapping nowhere because their first hash_order bases occur nowhere in the text (a miss in a complete
  * hash_tab); counters beyond the ones the library knows read 0. */
 int sbwt_ctx_last_stats_ex(const sbwt_ctx *ctx, uint64_t *stats, uint32_t n);

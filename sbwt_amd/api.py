@@ -123,7 +123,7 @@ def lib():
     L.sbwt_ctx_last_timing.argtypes = [vp, p(C.c_float * 3)]
     L.sbwt_ctx_last_stats.argtypes = [vp, p(u64 * 4)]
     L.sbwt_ctx_last_timing_ex.argtypes = [vp, p(C.c_float * 5), u32]
-    L.sbwt_ctx_last_stats_ex.argtypes = [vp, p(u64 * 13), u32]
+    L.sbwt_ctx_last_stats_ex.argtypes = [vp, p(u64 * 14), u32]
     L.sbwt_probe_random_access.argtypes = [vp, u32, u32, u32, p(C.c_double), p(u64)]
     L.sbwt_probe_gather_stream.argtypes = [vp, u64, u32, p(C.c_double)]
     L.sbwt_ctx_stream.argtypes = [vp]
@@ -430,8 +430,8 @@ class Context:
         return list(ms)
 
     def last_stats_ex(self):
-        st = (C.c_uint64 * 13)()
-        _check(lib().sbwt_ctx_last_stats_ex(self._h, C.byref(st), 13))
+        st = (C.c_uint64 * 14)()
+        _check(lib().sbwt_ctx_last_stats_ex(self._h, C.byref(st), 14))
         return list(st)
 
     def close(self):

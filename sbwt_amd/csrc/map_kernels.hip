@@ -168,7 +168,7 @@ static uint32_t debug_knob(const char* name, uint32_t dflt) {
 // What one device pass needs besides its inputs and outputs: the stream, the scratch buffers of the kernels and the
 // launch shapes.  A sbwt_ctx owns one (hipMalloc at sbwt_ctx_create); sbwt_map_batch_device_static points one at
 // the file-scope scratch array of the device.
-constexpr int kNumStats = 13;  // sbwt_ctx_last_stats_ex
+constexpr int kNumStats = 14;  // sbwt_ctx_last_stats_ex
 constexpr uint32_t kModeSkipHash = 1u << 31;  // internal mode bit of map_pass: every read of the batch already missed hash_tab
 
 struct MapWork {
@@ -188,7 +188,7 @@ struct MapWork {
   unsigned long long* d_group_keys = nullptr; // grouping of multi-hit reads with one interval and length (multi_locate.h)
   uint32_t* d_group_leader = nullptr;
   uint32_t group_slots = 0;                   // a power of two; 0: no grouping (the no-allocation entry point)
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // null: the pass is not timed
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // null: the pass is not timed ([3], [4]: around locate kernels launched in a second phase)
   // test knobs (environment variables, read ONCE: when the ctx is made, or -- the entry point without a ctx -- the index)
   bool no_bfs = false, no_chain = false;
   uint32_t ring_width_max = (uint32_t)kRingWidthMax, ring_chr_max = 0xFFFFu;
@@ -207,7 +207,7 @@ struct sbwt_ctx : MapWork {
   hipStream_t s_in = nullptr, s_out = nullptr;  // copies of the sub-batched host-buffer path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k = nullptr;
   float last_ms[3] = {0, 0, 0};
-  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t last_stats[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging for the host-buffer entry point
   uint32_t *d_packed = nullptr, *d_lens = nullptr;
   sbwt_read_result* d_results = nullptr;
@@ -224,7 +224,7 @@ struct sbwt_ctx : MapWork {
   hipEvent_t ev_s[2] = {nullptr, nullptr};
   uint32_t grid_settle = 0, grid_direct = 0;
   float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
-  bool no_settle = false, no_direct = false;  // test knobs, read when the ctx is made
+  bool no_settle = false, no_direct = false, no_spec = false;  // test knobs, read when the ctx is made
   uint64_t subbatch = 2u << 20;               // reads per sub-batch of the host-buffer entry points (SBWT_SUBBATCH; 0 = never split)
 };
 
@@ -271,10 +271,11 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   read_pass_knobs(&c->no_bfs, &c->no_chain, &c->ring_width_max, &c->ring_chr_max);
   c->no_settle = getenv("SBWT_NO_SETTLE") != nullptr;
   c->no_direct = getenv("SBWT_NO_DIRECT") != nullptr;
+  c->no_spec = getenv("SBWT_NO_SPECULATIVE_PENDING") != nullptr;
   if (const char* sb = getenv("SBWT_SUBBATCH")) c->subbatch = strtoull(sb, nullptr, 10);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc(&c->d_ctr, sizeof(Counters));
-  if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, sizeof(Counters));
+  if (e == hipSuccess) e = hipMalloc(&c->d_ctr, 2 * sizeof(Counters));  // [0] the general kernels, [1] the fast pass
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, 2 * sizeof(Counters));
   if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&c->d_dfs_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess && ix->d.hash_text) e = hipMalloc(&c->d_pend_list, max_reads * sizeof(uint32_t));
@@ -301,7 +302,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   c->multi_lanes = 256u * 1024u;
   if (c->multi_lanes > max_reads) c->multi_lanes = (uint32_t)((max_reads + 255) / 256 * 256);
   if (e == hipSuccess) e = hipMalloc(&c->d_stacks, (uint64_t)c->multi_lanes * ix->d.interval * sizeof(Frame));
-  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+  for (int k = 0; k < 5 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking);
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming);
@@ -333,7 +334,7 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_pend_list); hipFree(c->d_pend_packed); hipFree(c->d_pend_lens); hipFree(c->d_pend_out); hipFree(c->d_pend_res); hipFree(c->d_pend_hits);
   for (int k = 0; k < 2; ++k)
     if (c->ev_s[k]) hipEventDestroy(c->ev_s[k]);
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < 5; ++k)
     if (c->ev[k]) hipEventDestroy(c->ev[k]);
   for (int k = 0; k < 2; ++k)
     if (c->ev_in[k]) hipEventDestroy(c->ev_in[k]);
@@ -430,11 +431,22 @@ extern "C" int sbwt_map_batch_device(sbwt_ctx* c, const uint32_t* d_packed, cons
   return rc;
 }
 
-static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
-                    uint32_t words_per_read, int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits,
-                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate,
-                    float* ms_out, uint64_t* stats_out) {
+// One device pass over a batch, in three pieces so that the pending pass of a fast pass can be launched before the
+// host knows how many reads it holds:
+//   pass_search   counters zeroed, k_search_sm (the batch size possibly read from device memory), k_multi_plan
+//   pass_multi    the locate kernels of the queued multi-hit reads (the host knows the batch size by then)
+//   pass_collect  the counters (copied back and synchronised by the caller) into timings, statistics and the verdict
+struct PassState {
   MapArgs a;
+  MultiSortArgs ms;
+  uint32_t n_waves = 0;
+};
+
+static int pass_search(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                       uint32_t words_per_read, int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits,
+                       uint64_t hits_cap, uint64_t multi_base, const unsigned long long* n_reads_dev,
+                       const unsigned long long* hash_skip_dev, PassState* P) {
+  MapArgs& a = P->a;
   a.packed = d_packed;
   a.lens = d_lens;
   a.n_reads = n_reads;
@@ -450,8 +462,6 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
   const bool timed = w.ev[0] != nullptr;
   if (timed) SBWT_HIP(hipEventRecord(w.ev[0], w.stream));
   const DeviceIndex& d = ix->d;
-  uint32_t n_waves = 0;
-  uint64_t chunk = 0;
   {
     SmArgs sa;
     sa.packed = d_packed;
@@ -466,6 +476,8 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     sa.wide_cap = io.wide_cap;
     sa.wide_count = &w.d_ctr->wide_count;
     sa.skip_hash = (mode & kModeSkipHash) ? 1u : 0u;
+    sa.n_reads_dev = n_reads_dev;
+    sa.hash_skip_dev = hash_skip_dev;
     sa.hits = io.unique_hits ? io.unique_hits : d_hits;
     sa.hits_cap = hits_cap;
     sa.multi_queue = w.d_queue;
@@ -484,16 +496,14 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     else if (long_reads) k_search_sm<false, true><<<grid, 256, w.sm_ring_bytes, w.stream>>>(d, sa);
     else k_search_sm<false, false><<<grid, 256, w.sm_ring_bytes, w.stream>>>(d, sa);
     SBWT_LAUNCHED();
-    n_waves = grid * 4;
-    chunk = ((n_reads + n_waves - 1) / n_waves + 63) & ~63ull;  // as k_search_sm splits the batch
+    P->n_waves = grid * 4;
   }
   if (timed) SBWT_HIP(hipEventRecord(w.ev[1], w.stream));
   {
-    // multi-hit reads: gather + sort where the tables allow it, the upstream depth-first walk for the rest
-    k_multi_plan<<<1, 1024, 0, w.stream>>>(w.d_wave_info, n_waves, multi_base, hits_cap, &w.d_ctr->hit_count,
+    k_multi_plan<<<1, 1024, 0, w.stream>>>(w.d_wave_info, P->n_waves, multi_base, hits_cap, &w.d_ctr->hit_count,
                                            &w.d_ctr->multi_count, &w.d_ctr->overflow);
     SBWT_LAUNCHED();
-    MultiSortArgs ms;
+    MultiSortArgs& ms = P->ms;
     ms.lens = d_lens;
     ms.strand = strand;
     ms.io = io;
@@ -501,8 +511,8 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     ms.multi_base = multi_base;
     ms.queue = w.d_queue;
     ms.wave_info = w.d_wave_info;
-    ms.n_waves = n_waves;
-    ms.chunk = chunk;
+    ms.n_waves = P->n_waves;
+    ms.chunk = 0;  // pass_multi
     ms.queue_count = &w.d_ctr->multi_count;
     ms.overflow = &w.d_ctr->overflow;
     ms.dfs_queue = w.d_dfs_queue;
@@ -514,6 +524,18 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
     ms.grp.keys = nullptr;
     ms.grp.leader = nullptr;
     ms.grp.mask = 0;
+  }
+  return SBWT_OK;
+}
+
+// multi-hit reads: gather + sort where the tables allow it, memoised chains or the upstream depth-first walk for the rest
+static int pass_multi(const sbwt_index* ix, const MapWork& w, PassState& P, uint64_t n_reads) {
+  const DeviceIndex& d = ix->d;
+  MultiSortArgs& ms = P.ms;
+  const MapArgs& a = P.a;
+  const uint32_t n_waves = P.n_waves;
+  ms.chunk = ((n_reads + n_waves - 1) / n_waves + 63) & ~63ull;  // as k_search_sm split the batch
+  {
     if (w.group_slots) {
       uint32_t slots = 1u << 12;  // as many as this batch can fill, at most what the ctx holds
       while (slots < n_reads && slots < w.group_slots) slots <<= 1;
@@ -557,10 +579,12 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
       SBWT_LAUNCHED();
     }
   }
-  if (timed) SBWT_HIP(hipEventRecord(w.ev[2], w.stream));
-  SBWT_HIP(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, w.stream));
-  SBWT_HIP(hipStreamSynchronize(w.stream));
-  SBWT_HIP(hipGetLastError());
+  return SBWT_OK;
+}
+
+static int pass_collect(const MapWork& w, const ResultIO& io, uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used,
+                        uint64_t* wide_used, bool accumulate, float* ms_out, uint64_t* stats_out, bool second_phase) {
+  const bool timed = w.ev[0] != nullptr;
 #ifdef SBWT_PHASE_CLOCKS
   {
     unsigned long long ph[24] = {0}, zero[24] = {0};
@@ -580,6 +604,12 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
       hipEventElapsedTime(&ms[0], w.ev[0], w.ev[2]);
       hipEventElapsedTime(&ms[1], w.ev[0], w.ev[1]);
       hipEventElapsedTime(&ms[2], w.ev[1], w.ev[2]);
+      if (second_phase) {  // the locate kernels ran after the counters had been read once
+        float more = 0.f;
+        hipEventElapsedTime(&more, w.ev[3], w.ev[4]);
+        ms[0] += more;
+        ms[2] += more;
+      }
     }
     for (int k = 0; k < 3; ++k) ms_out[k] = accumulate ? ms_out[k] + ms[k] : ms[k];
   }
@@ -613,6 +643,21 @@ static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_pa
   return SBWT_OK;
 }
 
+static int map_pass(const sbwt_index* ix, const MapWork& w, const uint32_t* d_packed, const uint32_t* d_lens, uint64_t n_reads,
+                    uint32_t words_per_read, int limit, int strand, const ResultIO& io, uint32_t mode, sbwt_hit* d_hits,
+                    uint64_t hits_cap, uint64_t multi_base, uint64_t* multi_used, uint64_t* wide_used, bool accumulate,
+                    float* ms_out, uint64_t* stats_out) {
+  PassState P;
+  if (int rc = pass_search(ix, w, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, multi_base,
+                           nullptr, nullptr, &P)) return rc;
+  if (int rc = pass_multi(ix, w, P, n_reads)) return rc;
+  if (w.ev[0]) SBWT_HIP(hipEventRecord(w.ev[2], w.stream));
+  SBWT_HIP(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, w.stream));
+  SBWT_HIP(hipStreamSynchronize(w.stream));
+  SBWT_HIP(hipGetLastError());
+  return pass_collect(w, io, hits_cap, multi_base, multi_used, wide_used, accumulate, ms_out, stats_out, false);
+}
+
 template <typename T>
 static int ensure(T** p, uint64_t* have, uint64_t need);
 
@@ -633,7 +678,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   if (!settle && !direct) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
-      c->last_stats[6] = c->last_stats[7] = c->last_stats[10] = 0;
+      c->last_stats[6] = c->last_stats[7] = c->last_stats[10] = c->last_stats[13] = 0;
     }
     return map_pass(c->ix, *c, d_packed, d_lens, n_reads, words_per_read, limit, strand, io, mode, d_hits, hits_cap, multi_base,
                     multi_used, wide_used, accumulate, c->last_ms, c->last_stats);
@@ -648,15 +693,15 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.results = io.results;
   sa.hits = d_hits;
   sa.pending_list = c->d_pend_list;
-  sa.pending_count = &c->d_ctr->pending_count;
-  sa.index_accesses = &c->d_ctr->index_accesses;
-  sa.hash_stats = c->d_ctr->hash_stats;
-  sa.pending_other = &c->d_ctr->pending_other;
-  sa.absent_count = &c->d_ctr->absent_count;
+  sa.pending_count = &c->d_ctr[1].pending_count;
+  sa.index_accesses = &c->d_ctr[1].index_accesses;
+  sa.hash_stats = c->d_ctr[1].hash_stats;
+  sa.pending_other = &c->d_ctr[1].pending_other;
+  sa.absent_count = &c->d_ctr[1].absent_count;
   sa.lds_tables = c->sort_lds_bytes ? 1u : 0u;
   sa.ring_chr_max = c->ring_chr_max;
   sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
-  SBWT_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+  SBWT_HIP(hipMemsetAsync(c->d_ctr + 1, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
   if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
@@ -680,19 +725,73 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   }
   SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev_s[1], c->stream));
-  SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-  SBWT_HIP(hipStreamSynchronize(c->stream));
-  const uint64_t n_pending = c->h_ctr->pending_count;
-  const bool all_missed = c->h_ctr->pending_other == 0;  // then the general kernels skip the hash table for this batch
-  const uint64_t s_acc = c->h_ctr->index_accesses, s_look = c->h_ctr->hash_stats[0], s_found = c->h_ctr->hash_stats[1];
-  const uint64_t s_absent = c->h_ctr->absent_count;
-  float ms_settle = 0.f;
-  hipEventElapsedTime(&ms_settle, c->ev_s[0], c->ev_s[1]);
+  Counters* const hf = c->h_ctr + 1;  // the fast pass counts in the second Counters of the ctx: the general kernels zero the first
   int rc = SBWT_OK;
   *multi_used = 0;
   if (wide_used) *wide_used = 0;
+  float ms3[3] = {0, 0, 0};
+  uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t n_pending = 0;
+  bool pending_done = false;
+  auto scatter = [&](uint64_t n, const unsigned long long* n_dev) -> hipError_t {
+    if (plain)
+      k_scatter_pending_plain<<<grid_items(n, 256), 256, 0, c->stream>>>(c->d_pend_res, c->d_pend_hits, c->d_pend_list, n, io.results, d_hits, n_dev);
+    else
+      k_scatter_pending<<<grid_items(n, 256), 256, 0, c->stream>>>(c->d_pend_out, c->d_pend_list, n, io.compact, n_dev);
+    return hipGetLastError();
+  };
+  // The pending pass WITHOUT waiting for the fast pass: gather, search kernel and scatter take the number of pending reads
+  // from device memory (the buffers of an earlier call bound it), the counters of both passes come back in one copy and the
+  // stream is synchronised once.  Only when the batch turns out to hold multi-hit reads do the locate kernels run, with the
+  // records scattered again behind them; a batch that outgrew the buffers is done over below.
+  uint64_t room = std::min<uint64_t>(std::min(c->pend_lens_cap, c->pend_words / 12), plain ? std::min(c->pend_res_cap, c->pend_hits_cap) : c->pend_out_cap);
+  room = std::min(room, n_reads);
+  if (room && !c->no_spec) {
+    const unsigned long long* n_dev = &c->d_ctr[1].pending_count;
+    k_gather_pending<<<grid_items(room, 256), 256, 0, c->stream>>>(d_packed, d_lens, c->d_pend_list, room, words_per_read / 4,
+                                                                    c->d_pend_packed, c->d_pend_lens, n_dev);
+    SBWT_LAUNCHED();
+    const ResultIO io2 = plain ? ResultIO{c->d_pend_res, nullptr, nullptr, 0, c->d_pend_hits} : ResultIO{nullptr, c->d_pend_out, io.wide, io.wide_cap};
+    PassState P;
+    if (int e = pass_search(c->ix, *c, c->d_pend_packed, c->d_pend_lens, room, words_per_read, limit, strand, io2, mode, d_hits, hits_cap,
+                            multi_base, n_dev, &c->d_ctr[1].pending_other, &P)) return e;
+    SBWT_HIP(hipEventRecord(c->ev[2], c->stream));
+    SBWT_HIP(scatter(room, n_dev));
+    SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, 2 * sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    SBWT_HIP(hipStreamSynchronize(c->stream));
+    SBWT_HIP(hipGetLastError());
+    n_pending = hf->pending_count;
+    if (n_pending <= room) {
+      pending_done = true;
+      bool second = false;
+      if (n_pending && c->h_ctr->multi_count && !c->h_ctr->overflow) {
+        second = true;
+        SBWT_HIP(hipEventRecord(c->ev[3], c->stream));
+        if (int e = pass_multi(c->ix, *c, P, n_pending)) return e;
+        SBWT_HIP(hipEventRecord(c->ev[4], c->stream));
+        SBWT_HIP(scatter(n_pending, nullptr));
+        SBWT_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+        SBWT_HIP(hipStreamSynchronize(c->stream));
+        SBWT_HIP(hipGetLastError());
+      }
+      if (n_pending) {
+        rc = pass_collect(*c, io2, hits_cap, multi_base, multi_used, wide_used, false, ms3, st, second);
+        if (rc != SBWT_OK && rc != SBWT_ERR_CAPACITY) return rc;
+      }
+    }
+  } else {
+    SBWT_HIP(hipMemcpyAsync(hf, c->d_ctr + 1, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    SBWT_HIP(hipStreamSynchronize(c->stream));
+    n_pending = hf->pending_count;
+  }
+  const bool all_missed = hf->pending_other == 0;  // then the general kernels skip the hash table for this batch
+  const uint64_t s_acc = hf->index_accesses, s_look = hf->hash_stats[0], s_found = hf->hash_stats[1];
+  const uint64_t s_absent = hf->absent_count;
+  float ms_settle = 0.f;
+  hipEventElapsedTime(&ms_settle, c->ev_s[0], c->ev_s[1]);
   float ms_pending = 0.f;
-  if (n_pending) {
+  if (n_pending && !pending_done) {
+    // the first batch of a ctx, or one with more pending reads than the buffers hold: sized now, then the same pass
     if (c->pend_out_cap < n_pending) {  // grown with a quarter to spare, so that batches of similar make-up reuse it
       const uint64_t want = std::min<uint64_t>(c->max_reads, n_pending + (n_pending >> 2));
       if (int e = ensure(&c->d_pend_packed, &c->pend_words, want * 12)) return e;  // (records of up to twelve words)
@@ -705,32 +804,27 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
       if (int e = ensure(&c->d_pend_hits, &c->pend_hits_cap, want)) return e;
     }
     k_gather_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(d_packed, d_lens, c->d_pend_list, n_pending, words_per_read / 4,
-                                                                         c->d_pend_packed, c->d_pend_lens);
+                                                                         c->d_pend_packed, c->d_pend_lens, nullptr);
     SBWT_LAUNCHED();
     const ResultIO io2 = plain ? ResultIO{c->d_pend_res, nullptr, nullptr, 0, c->d_pend_hits} : ResultIO{nullptr, c->d_pend_out, io.wide, io.wide_cap};
-    float ms3[3] = {0, 0, 0};
-    uint64_t st[kNumStats] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     rc = map_pass(c->ix, *c, c->d_pend_packed, c->d_pend_lens, n_pending, words_per_read, limit, strand, io2,
                   mode | (all_missed ? kModeSkipHash : 0u), d_hits, hits_cap, multi_base,
                   multi_used, wide_used, false, ms3, st);
     if (rc != SBWT_OK && rc != SBWT_ERR_CAPACITY) return rc;
-    if (plain)
-      k_scatter_pending_plain<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(c->d_pend_res, c->d_pend_hits, c->d_pend_list, n_pending,
-                                                                                 io.results, d_hits);
-    else
-      k_scatter_pending<<<grid_items(n_pending, 256), 256, 0, c->stream>>>(c->d_pend_out, c->d_pend_list, n_pending, io.compact);
-    SBWT_LAUNCHED();
+    SBWT_HIP(scatter(n_pending, nullptr));
     SBWT_HIP(hipStreamSynchronize(c->stream));
+  }
+  if (n_pending) {
     ms_pending = ms3[0];
     const float add[3] = {ms_settle + ms3[0], ms_settle + ms3[1], ms3[2]};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent, st[11], st[12]};
+    const uint64_t sadd[kNumStats] = {s_acc + st[0], st[1], 0, st[3], s_look + st[4], s_found + st[5], s_acc, n_pending, st[8], st[9], s_absent, st[11], st[12], pending_done ? 1u : 0u};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   } else {
     const float add[3] = {ms_settle, ms_settle, 0.f};
     for (int k = 0; k < 3; ++k) c->last_ms[k] = accumulate ? c->last_ms[k] + add[k] : add[k];
-    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent, 0, 0};
+    const uint64_t sadd[kNumStats] = {s_acc, 0, 0, 0, s_look, s_found, s_acc, 0, 0, 0, s_absent, 0, 0, pending_done ? 1u : 0u};
     for (int k = 0; k < kNumStats; ++k)
       if (k != 2) c->last_stats[k] = (accumulate ? c->last_stats[k] : 0) + sadd[k];
   }

@@ -167,6 +167,10 @@ struct SmArgs {
   unsigned long long* wide_count;
   uint64_t wide_cap;
   uint32_t skip_hash;  // the batch holds only reads whose prefix is known not to be in hash_tab (k_settle looked them up)
+  // the pending pass of a fast pass, launched before the host knows how many reads it left: the batch holds
+  // min(*n_reads_dev, n_reads) reads, and skips hash_tab when *hash_skip_dev == 0 (null: n_reads / skip_hash as given)
+  const unsigned long long* n_reads_dev;
+  const unsigned long long* hash_skip_dev;
 };
 
 constexpr uint32_t kSmMaxKeys = 1536;   // chr + npos entries staged in LDS (chr 8 B, npos 16 B each)
@@ -286,12 +290,18 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  uint64_t chunk = (a.n_reads + n_waves - 1) / n_waves;
+  uint64_t n_reads = a.n_reads;
+  if (a.n_reads_dev) {
+    const uint64_t nd = *a.n_reads_dev;
+    n_reads = nd < n_reads ? nd : n_reads;
+  }
+  uint64_t chunk = (n_reads + n_waves - 1) / n_waves;
   chunk = (chunk + 63) & ~63ull;
-  const uint64_t range_begin = wave * chunk;
-  const uint64_t range_end = range_begin + chunk < a.n_reads ? range_begin + chunk : a.n_reads;
+  const uint64_t range_begin = wave * chunk < n_reads ? wave * chunk : n_reads;
+  const uint64_t range_end = range_begin + chunk < n_reads ? range_begin + chunk : n_reads;
   const uint32_t K = ix.kmer_order;
-  const uint32_t H = a.skip_hash ? 0u : ix.hash_order;  // 0: no hash table
+  const bool skip_hash = a.skip_hash || (a.hash_skip_dev && *a.hash_skip_dev == 0ull);
+  const uint32_t H = skip_hash ? 0u : ix.hash_order;  // 0: no hash table
   const uint64_t hmask = (1ull << (2 * H)) - 1ull;
   const uint64_t kmask = (1ull << (2 * K)) - 1ull;  // K <= kMaxKmerOrder: the prefix lies in the first 32 bases, w_lo
   const uint32_t max_len = a.wpr * 16u;
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
     if (st != S_IDLE) {
       if (free_r) {
         const uint64_t q = !(pf & PF_W1) ? rn : rn2;
-        if (!(pf & PF_W2) && q + 1 < a.n_reads && q < range_end) {
+        if (!(pf & PF_W2) && q + 1 < n_reads && q < range_end) {
           pr = reinterpret_cast<const uint4*>(a.packed + q * (uint64_t)a.wpr);
           pl = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(a.lens + q) & ~(uintptr_t)7);
           pf |= !(pf & PF_W1) ? PF_RW1 : PF_RW2;

@@ -259,8 +259,10 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
 // the pending reads as a dense batch: record (`pieces` 16-byte pieces) and length of read list[i] at slot i
 __global__ __launch_bounds__(256) void k_gather_pending(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ lens,
                                                         const uint32_t* __restrict__ list, uint64_t n_pending, uint32_t pieces,
-                                                        uint32_t* __restrict__ packed2, uint32_t* __restrict__ lens2) {
+                                                        uint32_t* __restrict__ packed2, uint32_t* __restrict__ lens2,
+                                                        const unsigned long long* __restrict__ n_dev) {
   const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev && *n_dev < n_pending) n_pending = *n_dev;  // (launched before the host knows the count: n_pending is the room)
   if (i >= n_pending) return;
   const uint32_t r = list[i];
   for (uint32_t k = 0; k < pieces; ++k)
@@ -272,8 +274,10 @@ __global__ __launch_bounds__(256) void k_gather_pending(const uint32_t* __restri
 // the caller's (hits); the lists of multi-hit reads are where the caller's first_hit already points
 __global__ __launch_bounds__(256) void k_scatter_pending_plain(const sbwt_read_result* __restrict__ from, const sbwt_hit* __restrict__ hits_from,
                                                                const uint32_t* __restrict__ list, uint64_t n_pending,
-                                                               sbwt_read_result* __restrict__ out, sbwt_hit* __restrict__ hits) {
+                                                               sbwt_read_result* __restrict__ out, sbwt_hit* __restrict__ hits,
+                                                               const unsigned long long* __restrict__ n_dev) {
   const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev && *n_dev < n_pending) n_pending = *n_dev;
   if (i >= n_pending) return;
   sbwt_read_result res = from[i];
   const uint32_t r = list[i];
@@ -285,8 +289,10 @@ __global__ __launch_bounds__(256) void k_scatter_pending_plain(const sbwt_read_r
 }
 
 __global__ __launch_bounds__(256) void k_scatter_pending(const sbwt_compact_result* __restrict__ from, const uint32_t* __restrict__ list,
-                                                         uint64_t n_pending, sbwt_compact_result* __restrict__ out) {
+                                                         uint64_t n_pending, sbwt_compact_result* __restrict__ out,
+                                                         const unsigned long long* __restrict__ n_dev) {
   const uint64_t i = (uint64_t)blockIdx.y * gridDim.x * blockDim.x + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev && *n_dev < n_pending) n_pending = *n_dev;
   if (i >= n_pending) return;
   reinterpret_cast<uint4*>(out)[list[i]] = reinterpret_cast<const uint4*>(from)[i];
 }

@@ -444,6 +444,51 @@ def test_32_byte_records_take_the_two_access_fast_pass(world, monkeypatch, lens_
     monkeypatch.delenv("SBWT_NO_DIRECT", raising=False)
 
 
+@pytest.mark.parametrize("layout", ["hits", "compact", "plain"])
+def test_pending_pass_launched_without_waiting_for_the_fast_pass(world, monkeypatch, layout):
+    """Calls in a row on ONE ctx.  The first sizes the buffers of the pending reads on the host; from the second on gather,
+    search kernel and scatter are launched with the count still in device memory (last_stats_ex [13]) and the locate
+    kernels only when the batch turns out to hold multi-hit reads; a batch with more pending reads than the buffers hold
+    is done over the first way.  Every call equals the oracle, and the path that always waits (the knob)."""
+    sb, ix, oix, codes, fam, rng = world
+    fam_reads = [bytes(b"ACGT"[c] for c in f[a:b]) for f in fam[:12] for a, b in ((0, 30), (3, 28))]
+    batches = [sample_reads(rng, codes, 3000, [32, 40, 50]) + fam_reads,            # sizes the buffers
+               sample_reads(rng, codes, 3000, [32, 40, 50]),                        # no multi-hit read left pending ...
+               sample_reads(rng, codes, 2500, [32, 40, 50]) + fam_reads * 2,        # ... multi-hit reads: the second phase
+               sample_reads(rng, codes, 3000, [60, 64]) + fam_reads,                # everything pending (hits only): outgrows the buffers
+               sample_reads(rng, codes, 2000, [36, 50], mutate=0.0)]
+    outs = {}
+    for knob in (False, True):
+        if knob:
+            monkeypatch.setenv("SBWT_NO_SPECULATIVE_PENDING", "1")
+        ctx = sb.Context(ix, max(len(b) for b in batches))
+        for bi, reads in enumerate(batches):
+            packed, lens = sb.pack_reads(reads)
+            if layout == "plain":
+                res, hits = ctx.map_batch(packed, lens)
+            else:
+                rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=sb.MAP_HITS_ONLY if layout == "hits" else 0)
+                res, hits = sb.compact_expand(rec, lists, wide)
+            st = ctx.last_stats_ex()
+            lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+            np.testing.assert_array_equal(res["nh"], nh)
+            k = np.maximum(nh, 0)
+            gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)]), (knob, bi)
+            if layout != "hits":
+                np.testing.assert_array_equal(res["sa_lo"], lo)
+                np.testing.assert_array_equal(res["sa_hi"], hi)
+            outs[(knob, bi)] = (int(st[7]), int(st[13]), int(st[1]))
+        ctx.close()
+    monkeypatch.delenv("SBWT_NO_SPECULATIVE_PENDING", raising=False)
+    # (the first call, and one that outgrows the buffers, wait -- unless the wrapper had to call twice for room in hits[])
+    assert outs[(False, 1)][1] == 1 and outs[(False, 2)][1] == 1 and outs[(False, 4)][1] == 1
+    assert outs[(False, 2)][2] > 0                           # multi-hit reads among the pending ones of the third call
+    assert all(outs[(True, b)][1] == 0 for b in range(5))    # the knob: always the waiting path
+    assert all(outs[(True, b)][0] == outs[(False, b)][0] for b in range(5))   # the same reads left pending either way
+
+
 def test_roofline_probes_run(world):
     """sbwt_probe_random_access / sbwt_probe_gather_stream: measurement entry points; here only that they run on a small
     index and report a rate"""
