@@ -592,7 +592,7 @@ static int pass_collect(const MapWork& w, const ResultIO& io, uint64_t hits_cap,
     SBWT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_multi_phase), zero, sizeof(zero)));
     fprintf(stderr, "k_multi_sort phase clocks (scan, record, sa_full, text, keys, decide, radix, compare-sort, write | reads, radix reads)\n");
     for (int t = 0; t < 2; ++t) {
-      fprintf(stderr, t ? "  k_multi_sort<256>:" : "  k_multi_bfs<256,512> (root, expand, big nodes, level end, sort, emit, -, -, -, rows | reads, levels):");
+      fprintf(stderr, t ? "  k_multi_sort<256>:" : "  k_multi_chain<256> (rows + entries, prune, emit + filters, sort, cut + write, -, -, -, -, entries | reads, radix reads):");
       for (int k = 0; k < 10; ++k) fprintf(stderr, " %.3g", (double)ph[12 * t + k]);
       fprintf(stderr, " | %llu %llu\n", ph[12 * t + 10], ph[12 * t + 11]);
     }

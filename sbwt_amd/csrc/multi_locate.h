@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
   }
 #ifdef SBWT_PHASE_CLOCKS
   team_sync<T>();
-  if (tid < 12 && T == 256 && kNodes == 512) atomicAdd(&g_multi_phase[tid], s_phase[team][tid]);
+  (void)s_phase;  // (the slots of g_multi_phase[0..12) now report k_multi_chain)
 #endif
 }
 
@@ -1081,6 +1081,12 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
   const uint64_t m_text = ix.n - 1;
   const uint32_t depth_max = (uint32_t)ix.interval - 1u;  // bases a chain can hold
   unsigned long long rows_done = 0, reads_done = 0;  // (thread 0 of a team; one atomic each when the kernel ends)
+#ifdef SBWT_PHASE_CLOCKS
+  __shared__ unsigned long long s_phase[4][12];
+  if (tid < 12) s_phase[team][tid] = 0;
+  team_sync<T>();
+  unsigned long long ph_t = clock64();
+#endif
   // the first d bases of a chain (d <= 63), zero padded
   auto prefix_of = [](ulonglong2 f, uint32_t d) -> ulonglong2 {
     if (d == 0) return make_ulonglong2(0, 0);
@@ -1166,6 +1172,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     }
     if (fail) cnt[0] = 1u;
     team_sync<T>();
+    SBWT_PHASE_MEM(0);
     // ---- a node of one sampled row has no children: an event at depth d >= 1 in a node no other chain passes through
     // ends its chain (only chains with several events can lose any)
 #pragma unroll
@@ -1197,6 +1204,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
       }
       n_ev[kk] = keep;
     }
+    SBWT_PHASE_MEM(1);
     // ---- entries: numbered thread by thread, i.e. in row order
     uint32_t H;
     uint32_t slot = team_excl_scan(n_ev[0] + n_ev[1] + n_ev[2] + n_ev[3], &H);
@@ -1205,33 +1213,75 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     team_sync<T>();  // every thread is done with kb (the sort may take it over) before anything else is written
     uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
     bool wrapped = false;
+    // the filters (push_position, searcher.hpp:504-539) of the rows' first events: the table searches of the four run interleaved
+    uint64_t fpos[4];
+    uint32_t c1[4], n1[4];
+    bool frc[4], fgo[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
-      for (uint32_t j = 0; j < n_ev[kk]; ++j) {
-        const uint64_t ev = j == 0 ? ev0[kk] : evs[j - 1];
-        const uint32_t d = (uint32_t)(ev >> 58);
-        const ulonglong2 pre = prefix_of(full[kk], d);
-        const ulonglong2 key = sort_key(pre.x, pre.y, d);
+      fpos[kk] = ev0[kk] & kPosMask;
+      frc[kk] = false;
+      fgo[kk] = n_ev[kk] != 0 && push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
+      if (!fgo[kk]) fpos[kk] = 0;
+    }
+    upper_bound_minus1_x4(t_chr, ix.n_chr, fpos, c1);
+    upper_bound_minus1_x4(t_nk, ix.n_npos, fpos, n1);
+    auto put = [&](uint32_t at, const ulonglong2& fullk, uint64_t ev, bool ok, const sbwt_hit& h) {
+      const uint32_t d = (uint32_t)(ev >> 58);
+      const ulonglong2 pre = prefix_of(fullk, d);
+      const ulonglong2 key = sort_key(pre.x, pre.y, d);
+      uint64_t py = (uint64_t)d << 58;
+      if (ok) {
+        if (h.pos0 > kPosMask) wrapped = true;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
+        py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+      }
+      ka[at] = key;
+      pay[at] = py;
+      or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y;
+    };
+    uint32_t at[4], max_ev = 0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      at[kk] = slot;
+      slot += n_ev[kk];
+      max_ev = n_ev[kk] > max_ev ? n_ev[kk] : max_ev;
+      if (n_ev[kk]) {
         sbwt_hit h;
-        uint64_t py = (uint64_t)d << 58;
-        if (push_position_keys(ix, t_chr, t_nk, t_nv, ev & kPosMask, L, a.strand, &h)) {
-          if (h.pos0 > kPosMask) wrapped = true;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
-          py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
-        }
-        ka[slot] = key;
-        pay[slot] = py;
-        ++slot;
-        or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y;
+        const bool ok = fgo[kk] && push_position_finish(ix, t_chr, t_nk, t_nv, fpos[kk], L, frc[kk], c1[kk], n1[kk], &h);
+        put(at[kk], full[kk], ev0[kk], ok, h);
+      }
+    }
+    // the further events of the chains that have any: the four rows' loads of one round in flight together
+    for (uint32_t j = 1; j < max_ev; ++j) {
+      uint64_t ev[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ev[kk] = j < n_ev[kk] ? ix.chain_ev[(meta[kk] >> kChainEvOffShift) + j - 1] : 0ull;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        fpos[kk] = ev[kk] & kPosMask;
+        frc[kk] = false;
+        fgo[kk] = j < n_ev[kk] && push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
+        if (!fgo[kk]) fpos[kk] = 0;
+      }
+      upper_bound_minus1_x4(t_chr, ix.n_chr, fpos, c1);
+      upper_bound_minus1_x4(t_nk, ix.n_npos, fpos, n1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (j >= n_ev[kk]) continue;
+        sbwt_hit h;
+        const bool ok = fgo[kk] && push_position_finish(ix, t_chr, t_nk, t_nv, fpos[kk], L, frc[kk], c1[kk], n1[kk], &h);
+        put(at[kk] + j, full[kk], ev[kk], ok, h);
       }
     }
     if (wrapped) cnt[0] = 1u;
     team_sync<T>();
+    SBWT_PHASE_MEM(2);
     const bool failed2 = cnt[0] != 0;
     team_sync<T>();  // (nobody writes cnt[0] again before every thread has read it)
     if (failed2) continue;
     bool radix = false;
     const SortedRows sorted = team_sort_rows<T>(sort_lds, H, tid, lane, or0, and0, or1, and1, radix);
+    SBWT_PHASE(3);
     // ---- accepted hits before every place, node boundaries, the cut (as k_multi_bfs)
     uint32_t base = 0;
     for (uint32_t c = 0; c < H; c += T) {
@@ -1271,7 +1321,15 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
       rows_done += m;
       ++reads_done;
     }
+    SBWT_PHASE_MEM(4);
+#ifdef SBWT_PHASE_CLOCKS
+    if (tid == 0) { s_phase[team][10] += 1; s_phase[team][9] += H; s_phase[team][11] += radix ? 1 : 0; }
+#endif
   }
+#ifdef SBWT_PHASE_CLOCKS
+  team_sync<T>();
+  if (tid < 12 && T == 256) atomicAdd(&g_multi_phase[tid], s_phase[team][tid]);
+#endif
   if (tid == 0 && reads_done) {
     atomicAdd(chain_count, reads_done);
     atomicAdd(a.rows_count, rows_done);
