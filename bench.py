@@ -540,8 +540,7 @@ class Run:
             ghits = np.frombuffer(torch.where(in_list[:, None], got_l, got).cpu().numpy().tobytes(), dtype=self.sb.api.HIT_DTYPE)
             oi = (np.repeat(first, nh) + within).astype(np.int64)
             ok = bool(np.array_equal(ghits, ohits[oi]))
-        return {"reads_checked": probe_n, "identical": ok,
-                "compared": "NH and ordered hit lists of every read; SA intervals of the %d reads that report one" % int(sa_ok.sum())}, rate
+        return {"reads_checked": probe_n, "identical": ok, "sa_intervals_compared": int(sa_ok.sum())}, rate   # + NH and ordered hit lists of every read
 
     def accounting(self):
         """Algorithmic bytes of ONE launch of the dominant kernel: the search is a chain of random
@@ -567,7 +566,7 @@ class Run:
             # locate-bound workloads: the multi-hit kernels take most of the step; one text (or chain) line + the sa_full
             # word in and a 16-byte hit out per raw row, the search kernel's lines on top
             rows = int(stats[12]) if len(stats) > 12 else int(self.list_hits)   # raw rows located (a list several reads share: once)
-            A["kernel"], A["kernel_ms"] = "multi-hit locate (k_multi_sort / k_multi_chain)", A["multi_ms"]
+            A["kernel"], A["kernel_ms"] = "k_multi_sort+k_multi_chain", A["multi_ms"]
             A["accesses"] = rows
             A["streamed"] = rows * (8 + 16)
             A["rows_located"] = rows
@@ -577,22 +576,25 @@ class Run:
         A["all_accesses"] = int(stats[0])
         return A
 
-    def summary(self, name, workload, parity, world=1):
+    def summary(self, name, workload, parity, world=1, short=None):
         """one short entry of the `configs` block"""
         A = self.accounting()
         st = self.stats
-        return {"name": name, "workload": workload, "layout": self.layout,
-                "reads_per_s": round(world * self.n_reads * self.steps / self.elapsed, 1),
-                "ms_per_step": round(self.elapsed / self.steps * 1e3, 3),
-                "kernel": A["kernel"], "kernel_ms": round(A["kernel_ms"], 3),
-                "index_lines_per_read": round(A["all_accesses"] / self.n_reads, 3),
-                "achieved_GBps": round(A["achieved_GBps"], 1), "frac": round(A["achieved_GBps"] / 8000.0, 4),
-                "hash_hit_rate": round(st[5] / st[4], 4) if st[4] else None,
-                "mapped_reads": self.mapped, "multi_hit_reads": self.multi, "list_hits": int(self.list_hits),
-                "multi_locate_ms": round(A["multi_ms"], 3), "rows_located": int(st[12]) if len(st) > 12 else None,
-                "reads_off_the_text": int(st[3]), "of_which_from_chain_tab": int(st[11]) if len(st) > 11 else 0,
-                "parity_vs_oracle": parity["identical"] if parity else None,
-                "reads_checked": parity["reads_checked"] if parity else 0}
+        e = {"name": name, "layout": self.layout,
+             "reads_per_s": round(world * self.n_reads * self.steps / self.elapsed, 1),
+             "ms_per_step": round(self.elapsed / self.steps * 1e3, 3),
+             "kernel": A["kernel"], "kernel_ms": round(A["kernel_ms"], 3),
+             "lines_per_read": round(A["all_accesses"] / self.n_reads, 3),
+             "GBps": round(A["achieved_GBps"], 1), "frac": round(A["achieved_GBps"] / 8000.0, 4),
+             "hash_hit_rate": round(st[5] / st[4], 4) if st[4] else None,
+             "parity_vs_oracle": parity["identical"] if parity else None,
+             "reads_checked": parity["reads_checked"] if parity else 0}
+        if self.multi:     # locate-heavy workloads
+            e.update({"multi_hit_reads": self.multi, "list_hits": int(self.list_hits), "multi_locate_ms": round(A["multi_ms"], 3),
+                      "rows_located": int(st[12]), "reads_off_the_text": int(st[3]), "of_which_from_chain_tab": int(st[11])})
+        if short is None:
+            e["workload"] = workload
+        return e
 
     def close(self):
         if self.own_ctx and self.ctx is not None:
@@ -679,8 +681,8 @@ def file_path_case(torch, dev, sb, wl, cores, n_reads, L=50):
         ix2.close()
     finally:
         shutil.rmtree(tmpd, ignore_errors=True)
-    return {"name": "index files", "workload": "the headline's index written in the upstream file format (%.2f GB t_table.bwt), "
-            "loaded with sbwt_index_load, %d x %d-bp reads" % (file_gb, n_reads, L), "layout": "compact",
+    return {"name": "index_files", "workload": "the headline's index saved in the upstream file format (%.2f GB t_table.bwt) and "
+            "loaded by sbwt_index_load, %d x %d bp" % (file_gb, n_reads, L), "layout": "compact",
             "index_save_s": round(t_save, 1), "index_load_s": round(t_load, 1),
             "reads_per_s": round(n_reads / (ms_loaded * 1e-3), 1), "device_ms_loaded": round(ms_loaded, 3),
             "device_ms_built": round(ms_built, 3), "index_hbm_GB": round(info2.device_bytes / 1e9, 2),
@@ -921,9 +923,7 @@ def main():
                           "hbm_requests_per_launch": t.get("hbm_requests_per_launch")}
     roofline = {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": stored["traffic_GB_per_launch"] if stored else None,
-                "traffic_source": stored["source"] if stored else None,
                 "launch_ms": round(dom_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
-                "algorithmic_bytes": "128 B per index line the kernel reads + streamed bytes (record and length in, result out); DESIGN.md section 3",
                 "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
                 "index_lines_per_s_G": round(lines_per_s, 2),
                 "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
@@ -969,7 +969,7 @@ def main():
                "host_cpus": os.cpu_count(),
                "sample": "first %d reads of the same batch, same index (reference-format tables), %d threads; "
                          "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n),
-               "note": "the port is about 2x the reference binary per thread (SURVEY.md section 6): a baseline beside the kernel, not the target"}
+               "note": "about 2x the reference binary per thread (SURVEY.md section 6)"}
         if not args.no_extras and args.min_len is None:
             # end to end, measured in this run (never `value`): (a) host buffers in, host buffers out through
             # page-locked memory (PCIe both ways), (b) FASTQ file -> SAM file with 16 host threads
@@ -1017,8 +1017,6 @@ def main():
             pin.close()
             shutil.rmtree(tmpd, ignore_errors=True)
             end_to_end = {"host_buffers_reads_per_s": round(n_e / best_c, 1) if best_c else None, "host_buffers_reads": n_e,
-                          "host_buffers_note": "sbwt_map_batch_compact (hits only), page-locked host buffers: H2D of packed reads (20 B per "
-                                               "read), kernels, D2H of the 16-byte records",
                           "host_buffers_plain_layout_reads_per_s": round(n_e / best, 1) if best else None,
                           "fastq_to_sam_reads_per_s": round(n_f / fbest, 1), "fastq_to_sam_reads": n_f, "host_threads": cores,
                           "fastq_MB": round(fq_bytes / 1e6), "sam_MB": round(sam_bytes / 1e6), "sam_records": int(st[4])}
@@ -1036,10 +1034,8 @@ def main():
                    "index_suffixes": int(info.n), "index_hbm_GB": round(info.device_bytes / 1e9, 2),
                    "search_prefix_tables": {"direct_order": int(info.kmer_order), "hash_order": int(info.hash_order)},
                    "suffix_order": "stopped at sort_len 256, ties shuffled" if args.shuffle_ties else "full",
-                   "result_layout": {"plain": "32-byte record + 16-byte hit slot per read (sbwt_map_batch_device)",
-                                     "compact": "16-byte record per read (sbwt_map_batch_device_compact)",
-                                     "hits": "16-byte record per read, SBWT_MAP_HITS_ONLY: hits, NH and flags of every read; no SA interval "
-                                             "for reads their located prefix settles (what the SAM output needs)"}[args.layout],
+                   "result_layout": {"plain": "32-byte records (sbwt_map_batch_device)", "compact": "16-byte records (sbwt_map_batch_device_compact)",
+                                     "hits": "16-byte records, SBWT_MAP_HITS_ONLY (what the SAM output needs)"}[args.layout],
                    "reads_per_gpu": n_reads, "read_len": L, "parallelism": "replicated index, reads sharded x%d" % world},
         "roofline": roofline, "cpu_baseline": cpu, "end_to_end": end_to_end, "cpu_baseline_config1": None,
         "detail": {"mapped_reads": head.mapped, "multi_hit_reads": head.multi, "list_hits": int(n_hits), "wide_records": head.n_wide_rec,
@@ -1078,13 +1074,13 @@ def main():
                 torch.cuda.empty_cache()
 
         steps_side = 3
-        w3 = "configs[2] (the headline's index and reads), SA intervals reported"
+        w3 = "configs[2], SA intervals reported"
         guarded("config3_intervals", lambda: side_case(torch, dev, sbwt_amd, olib, wl, "config3_intervals", w3, n_reads, L,
                                                        ["compact", "plain"], steps_side, cores, packed=packed, lens=lens))
         del packed, lens
         torch.cuda.empty_cache()
         guarded("config4_per_gpu", lambda: side_case(torch, dev, sbwt_amd, olib, wl, "config4_per_gpu",
-                                                     "configs[3] per GPU: the same index, %d x 100-bp reads" % n_reads, n_reads, 100,
+                                                     "configs[3] per GPU: %d x 100 bp" % n_reads, n_reads, 100,
                                                      ["hits", "compact"], steps_side, cores, seed=51))
         if run_cpu and not args.no_extras:
             guarded("index_files", lambda: file_path_case(torch, dev, sbwt_amd, wl, cores, n_reads // 10))
@@ -1095,7 +1091,7 @@ def main():
                 kw.setdefault("scale", args.scale)
                 w2 = Workload(torch, dev, sbwt_amd, want_tables=run_cpu, **kw)
                 try:
-                    out = side_case(torch, dev, sbwt_amd, olib, w2, name, workload % w2.describe(), n, rl, layouts, steps_side, cores,
+                    out = side_case(torch, dev, sbwt_amd, olib, w2, name, workload, n, rl, layouts, steps_side, cores,
                                     min_len=min_len, probe_n=probe_n)
                     for e in out:
                         e["index_suffixes"] = int(w2.info.n)
@@ -1106,13 +1102,13 @@ def main():
             guarded(name, fn)
 
         n_mid, n_small = n_reads // 5, n_reads // 10     # 2 x 10^7 and 10^7 in the full-size run
-        fresh("config2_dm6", "configs[1]: %%s, %d x 36-bp reads" % n_small, n_small, 36, ["hits", "compact"], scale=0.0486 * args.scale)
-        fresh("repeats", "%%s, %d x 50-bp reads" % n_mid, n_mid, 50, ["hits"], probe_n=5000, genome="repeats")
-        fresh("repeats_shuffled_ties", "%%s, suffix order stopped at sort_len 256 with ties shuffled (what upstream's builder "
-              "leaves), %d x 50-bp reads" % n_mid, n_mid, 50, ["hits"], probe_n=5000, genome="repeats", shuffle_ties=True)
-        fresh("config5_smallrna", "configs[4] per GPU: %%s, %d x 18..30-nt reads, half of them inside the family" % n_mid, n_mid, 30,
+        fresh("config2_dm6", "configs[1]: dm6-sized index, %d x 36 bp" % n_small, n_small, 36, ["hits", "compact"], scale=0.0486 * args.scale)
+        fresh("repeats", "40 %% of the genome in diverged repeat families, %d x 50 bp" % n_mid, n_mid, 50, ["hits"], probe_n=5000, genome="repeats")
+        fresh("repeats_shuffled_ties", "the same, suffix order stopped at sort_len 256 with ties shuffled (upstream's builder), %d x 50 bp" % n_mid,
+              n_mid, 50, ["hits"], probe_n=5000, genome="repeats", shuffle_ties=True)
+        fresh("config5_smallrna", "configs[4] per GPU: planted 30-mer family, %d x 18..30 nt" % n_mid, n_mid, 30,
               ["hits"], probe_n=5000, min_len=18, plant=True)
-        fresh("rank_path", "%%s, %d x 50-bp reads, no memoised search prefix (12-mer table + rank queries)" % n_reads, n_reads, 50,
+        fresh("rank_path", "no memoised search prefix (12-mer table + rank queries), %d x 50 bp" % n_reads, n_reads, 50,
               ["compact"], rank_path=True)
         if run_cpu and not args.no_extras:
             try:
