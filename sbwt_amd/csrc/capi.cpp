@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <memory>
 #include <new>
 #include <string>
@@ -65,6 +66,10 @@ static int make_index(int device, uint64_t interval, uint64_t n, uint64_t first_
                       const void* jbwt, const void* fbwt, const void* loc, uint64_t n_loc, ChrTables&& chr,
                       sbwt_index** out) {
   if (int rc = check_device(device)) return rc;
+  // SBWT_TIMING: where the seconds of a load go (stderr): file pages -> device, re-layout + prefix tables
+  const bool timing = getenv("SBWT_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   std::unique_ptr<sbwt_index> ix(new (std::nothrow) sbwt_index);
   if (!ix) return SBWT_ERR_NOMEM;
   ix->device = device;
@@ -97,9 +102,13 @@ static int make_index(int device, uint64_t interval, uint64_t n, uint64_t first_
     if (int rc = t_occ[c].upload(occ[c], occ_len * 8)) return rc;
     raw.occ[c] = static_cast<const uint64_t*>(t_occ[c].p);
   }
+  const double t1 = now();
   if (int rc = build_device_layout(ix.get(), raw)) return rc;
   if (int rc = upload_chr_tables(ix.get())) return rc;
   if (int rc = finish_index(ix.get())) return rc;
+  if (timing)
+    fprintf(stderr, "[sbwt timing] index on device %d: reference tables to the device %.2f s (the file's pages are read here), HBM layout "
+            "%.2f s (see SBWT_DEBUG for its parts), %.1f GB held\n", device, t1 - t0, now() - t1, (double)ix->device_bytes / 1e9);
   *out = ix.release();
   return SBWT_OK;
 }

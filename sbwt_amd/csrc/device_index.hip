@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 
 #include "index_impl.hpp"
@@ -819,6 +820,17 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
 
   const uint64_t nb = d.n_blocks;
   const uint64_t n_chunks = (nb + kChunk - 1) / kChunk;
+  // SBWT_TIMING: seconds per part of the layout (stderr); each mark waits for the device
+  const bool timing = getenv("SBWT_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const double t = now();
+    fprintf(stderr, "[sbwt timing]   layout: %-34s %.2f s\n", what, t - t_mark);
+    t_mark = t;
+  };
   Block1* blocks1 = nullptr;
   Block2* blocks2 = nullptr;
   uint64_t *loc_vals = nullptr, *sa_full = nullptr, *sb_abs = nullptr;
@@ -880,6 +892,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     }
   }
   d.sa_full = sa_full;
+  mark("blocks1, loc_vals, sa_full");
   if (raw.n >= (1ull << kPosBits)) {
     set_error("index has 2^40 suffixes or more");
     return -4;
@@ -918,6 +931,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     d.pos_lines = pos_lines;
     d.textrc = textrc;
   }
+  mark("row checks, textrc, runs, pos_lines");
 
   k_planes2<<<grid_for(nb * 64, 256), 256>>>(d, blocks2, d_small);
   SBWT_LAUNCHED();
@@ -934,6 +948,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
   d.sb_abs = sb_abs;
   d.chain_tab = nullptr;
   d.chain_ev = nullptr;
+  mark("blocks2");
   if (raw.interval <= 64 && raw.n + 64 < kPosMask && !getenv("SBWT_NO_CHAIN_TAB")) {
     // chain_tab (device_layout.h): entries for the rows sa_full + the text do not answer for.  A handful on a fully
     // sorted index (the ends of the text); every row within `interval` positions above an LF-inconsistent one on an index
@@ -981,6 +996,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       fprintf(stderr, "[sbwt debug] chain_tab: %llu of %llu rows need an entry, %llu further events: %s\n", (unsigned long long)n_chain,
               (unsigned long long)raw.n, h_extra, d.chain_tab ? "built" : (n_chain ? "too many, none built" : "none needed"));
   }
+  mark("chain_tab");
   {
     // widest order K <= 17 whose 4^K entries are at most 16 per suffix (beyond that nearly every K-mer that occurs
     // is a single row already) and whose table leaves kKmerHeadroom of this device's memory free (GRCh38: 17,
@@ -1113,6 +1129,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       d.hash_group = group;
       d.hash_complete = complete ? 1u : 0u;
     }
+    mark("hash_tab");
     d.kmer_order = K;
     d.kmer_tab = nullptr;
     uint64_t* tab = nullptr;
@@ -1128,6 +1145,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
     }
   }
   SBWT_HIP(hipDeviceSynchronize());
+  mark("kmer_tab");
   return 0;
 }
 

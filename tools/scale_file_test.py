@@ -106,7 +106,7 @@ def run(args, exe, d):
     r = subprocess.run([exe, "map", "-i", fq, "-p", prefix, "-o", sam, "-n", str(args.threads)], capture_output=True)
     dt = time.time() - t0
     print("sbwt map -n %d: rc %d, %.1f s for %d reads (index load included)\n%s" % (args.threads, r.returncode, dt, args.reads,
-          r.stderr.decode()[-400:]), flush=True)
+          r.stderr.decode()[-3000:]), flush=True)
     if r.returncode:
         raise SystemExit(1)
     # the oracle on the same index files, first --check reads
