@@ -673,11 +673,11 @@ __device__ __forceinline__ bool hash_insert(uint64_t* tab, uint64_t n_buckets, u
 // k_settle leaves the read to the general kernels), and a row the steps for ITS K-mer do not end on -- no K bases
 // behind it, not located, an order of suffixes the text does not explain -- goes to `uncovered` for k_hash_cover.
 __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, uint64_t* __restrict__ tab, uint64_t n_buckets,
-                                                    uint32_t tag_bits, uint32_t with_text, uint32_t group,
+                                                    uint32_t tag_bits, uint32_t with_text, uint32_t group, uint32_t twins,
                                                     unsigned long long* __restrict__ counts, uint64_t* __restrict__ uncovered,
                                                     uint64_t uncovered_cap) {
   const uint64_t i = global_thread();
-  uint32_t outcome = 0;  // 1 stored, 2 left out, 3 marker stored, 4 marker left out
+  uint32_t outcome = 0;  // 1 stored, 2 left out, 3 marker stored, 4 marker left out, 7 twin slots stored
   bool covered = false;
   const uint64_t e = i < ix.n ? ix.sa_full[i] : kNoPosition;
   const uint64_t p = e & kPosMask, run = e >> kPosBits;
@@ -707,21 +707,43 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
     covered = alive && lo <= i && i < hi;
     const uint64_t vv = hash_mix(v, K);
     const uint64_t tag = vv & ((1ull << tag_bits) - 1ull);
+    const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
+    // what the read's bases K .. K+31 are compared with: textrc[m - q ..) (search_machine.h, S_CMP: x0 = n - 1 - q)
+    auto text_behind = [&](uint64_t q) -> uint64_t {
+      const uint64_t x1 = m - q;
+      const uint32_t* ty = ix.textrc + (x1 >> 4);
+      const uint32_t sh1 = 2u * (uint32_t)(x1 & 15);
+      const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
+      return sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
+    };
     if (covered && hi - lo == 1 && run >= 1) {
-      const uint64_t run_max = (1ull << (24 - tag_bits)) - 1ull;
       const uint64_t slot = (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | tag;
-      uint64_t text = 0;
-      if (with_text) {
-        // what the read's bases K .. K+31 are compared with: textrc[m - p ..) (search_machine.h, S_CMP: x0 = n - 1 - p)
-        const uint64_t x1 = m - p;
-        const uint32_t* ty = ix.textrc + (x1 >> 4);
-        const uint32_t sh1 = 2u * (uint32_t)(x1 & 15);
-        const uint64_t u0 = ty[0] | ((uint64_t)ty[1] << 32), u1 = ty[2];
-        text = sh1 ? ((u0 >> sh1) | (u1 << (64 - sh1))) : u0;
-      }
-      outcome = hash_insert(tab, n_buckets, with_text, group, vv, K, slot, text) ? 1 : 2;
+      outcome = hash_insert(tab, n_buckets, with_text, group, vv, K, slot, with_text ? text_behind(p) : 0) ? 1 : 2;
     } else if (covered && with_text && i == lo) {
-      outcome = hash_insert(tab, n_buckets, with_text, group, vv, K, tag, 0) ? 3 : 4;  // position 0, run 0
+      // TWINS (device_layout.h): a K-mer on exactly two rows, both located, both with the K bases behind them in the text:
+      // each gets a slot of its own (kHashTwin), and a read whose further bases match ONE of the two texts is settled
+      // like any other.  A twin whose partner found no slot in the same bucket reads as a marker.
+      uint64_t e2 = kNoPosition;
+      if (twins && hi - lo == 2 && run >= 1) e2 = ix.sa_full[lo + 1];
+      const uint64_t p2 = e2 & kPosMask, run2 = e2 >> kPosBits;
+      bool twin = e2 != kNoPosition && run2 >= 1 && p2 + K <= m;
+      if (twin) {
+        const uint64_t y0 = m - p2 - K;
+        const uint32_t* tz = ix.textrc + (y0 >> 4);
+        const uint32_t sh2 = 2u * (uint32_t)(y0 & 15);
+        const uint64_t z0 = tz[0] | ((uint64_t)tz[1] << 32), z1 = tz[2];
+        const uint64_t bits2 = sh2 ? ((z0 >> sh2) | (z1 << (64 - sh2))) : z0;
+        twin = ((~bits2) & ((1ull << (2 * K)) - 1ull)) == v;
+      }
+      if (twin) {
+        const uint64_t s1 = kHashTwin | (p << 24) | ((run < run_max ? run : run_max) << tag_bits) | tag;
+        const uint64_t s2 = kHashTwin | (p2 << 24) | ((run2 < run_max ? run2 : run_max) << tag_bits) | tag;
+        const bool in1 = hash_insert(tab, n_buckets, with_text, group, vv, K, s1, text_behind(p));
+        const bool in2 = in1 && hash_insert(tab, n_buckets, with_text, group, vv, K, s2, text_behind(p2));
+        outcome = in2 ? 7 : in1 ? 3 : 4;
+      } else {
+        outcome = hash_insert(tab, n_buckets, with_text, group, vv, K, tag, 0) ? 3 : 4;  // position 0, run 0
+      }
     }
   }
   if (with_text && i < ix.n && !covered) {
@@ -729,7 +751,8 @@ __global__ __launch_bounds__(256) void k_hash_build(DeviceIndex ix, uint32_t K, 
     if (k < uncovered_cap) uncovered[k] = i;
   }
   // statistics: a few atomics per wave
-  for (uint32_t o = 1; o <= 4; ++o) {
+  for (uint32_t o = 1; o <= 7; ++o) {
+    if (o == 5 || o == 6) continue;  // (counts[4], counts[5]: uncovered rows, failed checks)
     const uint64_t mk = __ballot(outcome == o);
     if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&counts[o - 1], (unsigned long long)__popcll(mk));
   }
@@ -1074,7 +1097,7 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
       H = 0;
     }
     if (H) {
-      DevTemp<unsigned long long> d_counts;  // [0] stored, [1] left out, [2] markers, [3] markers left out, [4] uncovered rows, [5] failed checks
+      DevTemp<unsigned long long> d_counts;  // [0] stored, [1] left out, [2] markers, [3] markers left out, [4] uncovered rows, [5] failed checks, [6] twin pairs
       DevTemp<uint64_t> d_uncovered;
       SBWT_HIP(d_counts.alloc(8));
       // rows k_hash_build cannot account for: a handful on a fully sorted index, every row of an LF-inconsistent region
@@ -1103,7 +1126,9 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
           tag_bits = t;
         }
       }
-      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, group, d_counts, d_uncovered, uncovered_cap);
+      // twin slots flag themselves in the top bit of the position field: never set by a position (n < 2^39 - 2^8)
+      const uint32_t twins = with_text && raw.n < (1ull << 39) - 256 && !getenv("SBWT_NO_TWINS") ? 1u : 0u;
+      k_hash_build<<<grid_for(raw.n, 256), 256>>>(d, H, htab, n_buckets, tag_bits, with_text ? 1u : 0u, group, twins, d_counts, d_uncovered, uncovered_cap);
       SBWT_LAUNCHED();
       unsigned long long h_counts[8];
       SBWT_HIP(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost));
@@ -1119,8 +1144,8 @@ int build_device_layout(sbwt_index* ix, const RawDeviceTables& raw) {
         complete = h_counts[5] == 0;
       }
       if (getenv("SBWT_DEBUG"))
-        fprintf(stderr, "[sbwt debug] hash table: groups of %u buckets, %u tag bits; %llu prefixes stored, %llu left out (buckets full); %llu markers, %llu left out; %llu rows covered backwards, %llu failed checks: a miss %s\n",
-                group, tag_bits, h_counts[0], h_counts[1], h_counts[2], h_counts[3], h_counts[4], h_counts[5], complete ? "proves absence" : "proves nothing");
+        fprintf(stderr, "[sbwt debug] hash table: groups of %u buckets, %u tag bits; %llu prefixes stored, %llu left out (buckets full); %llu markers, %llu left out; %llu pairs of twin slots; %llu rows covered backwards, %llu failed checks: a miss %s\n",
+                group, tag_bits, h_counts[0], h_counts[1], h_counts[2], h_counts[3], h_counts[6], h_counts[4], h_counts[5], complete ? "proves absence" : "proves nothing");
       d.hash_tab = htab;
       d.hash_order = H;
       d.hash_buckets = n_buckets;

@@ -76,6 +76,14 @@ constexpr uint64_t kKmerRunMax = (1ull << 23) - 1;
 // buckets full are left out): a miss falls back to kmer_tab / c_functions, so the table never changes a result.
 // With hash_text every OTHER K-mer whose interval is not empty has a MARKER slot (run = 0: "occurs, not settled
 // here"), which is what lets a miss prove that a read maps nowhere (hash_complete).
+// TWINS: a K-mer whose interval is exactly TWO rows, both located, has two slots with the same tag, each with its own
+// position, run and text, flagged kHashTwin (the top bit of the position field; no position reaches it: n < 2^39).  Under
+// exec_exact_match a row of the interval survives a base iff its bwt character is that base, i.e. -- where LF-consistent --
+// iff the text in front of its position continues with it: a read whose further bases equal the text of ONE twin ends on
+// that twin's chain alone (one hit), of neither on an empty interval, of both stays with the general kernels.  A twin
+// whose partner is not in the same bucket, and a twin to any lookup that does not know twins, is a marker.
+constexpr uint64_t kHashTwin = 1ull << 63;
+constexpr uint64_t kHashPosMask = (1ull << 39) - 1ull;  // the position of a slot, twin or not: (slot >> 24) & kHashPosMask
 constexpr uint64_t kHashMul = 0x9E3779B97F4A7C15ull;
 constexpr uint32_t kHashSlots = 4;
 constexpr uint32_t kHashMaxOrder = 28;

@@ -114,16 +114,18 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
     if (look) ++looked;
-    uint64_t slot = ~0ull, text = 0;
+    uint64_t slot = ~0ull, text = 0, slot2 = ~0ull, text2 = 0;
     bool absent = false;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, lane, s_img, slot, text, absent, lines_n);  // (s_img: free until the lines arrive)
+    settle_lookup(ix, tab, bucket, tag, tmask, look, lane, s_img, slot, text, slot2, text2, absent, lines_n);  // (s_img: free until the lines arrive)
 
     bool missed = false;    // looked up and not in the table: the general kernels need not look again
     bool need_line = false; // second access: the PosLine of the position the read ends on
     uint64_t pfin = 0;
     if (look) {
-      const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
-      missed = slot == ~0ull || run == 0;  // (run 0: a marker -- the prefix occurs, on several rows or on one not located)
+      uint64_t pos = (slot >> 24) & kHashPosMask, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
+      const bool twin = slot != ~0ull && (slot & kHashTwin) != 0;
+      // (run 0: a marker -- the prefix occurs, on several rows or on one not located; so does a twin without its partner)
+      missed = slot == ~0ull || run == 0 || (twin && (slot2 == ~0ull || !(slot2 & kHashTwin)));
       if (slot == ~0ull && absent && ix.hash_complete && a.hits_only) {
         // the first H bases occur nowhere in the text: the upstream search ends on an empty interval (searcher.hpp:406)
         e1 = (uint64_t)R_NOSA << 56;
@@ -131,12 +133,22 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
         ++absent_n;
       } else if (!missed) {
         ++found_n;
-        if (run > (uint64_t)rem && pos >= (uint64_t)rem) {
-          // the first min(rem, 32) bases behind the prefix against the slot's text: a read that differs there needs no
-          // second access (no hit; its dead interval, when wanted, is the general kernels' business)
-          uint64_t r0, r1;
-          sm_funnel128(w0, w1, w2, w3, H, r0, r1);
-          const uint64_t diff = (r0 ^ text) & (rem < 32u ? (1ull << (2 * rem)) - 1ull : ~0ull);
+        // the first min(rem, 32) bases behind the prefix against the slot's text: a read that differs there needs no
+        // second access (no hit; its dead interval, when wanted, is the general kernels' business)
+        uint64_t r0, r1;
+        sm_funnel128(w0, w1, w2, w3, H, r0, r1);
+        const uint64_t cmask = rem < 32u ? (1ull << (2 * rem)) - 1ull : ~0ull;
+        uint64_t diff = (r0 ^ text) & cmask;
+        bool usable = run > (uint64_t)rem && pos >= (uint64_t)rem;
+        if (twin) {
+          // two rows hold the prefix (settle.h): the search goes on with the one whose text the read goes on with; when
+          // both do over these bases the general kernels take the read
+          const uint64_t pos2 = (slot2 >> 24) & kHashPosMask, run2 = (slot2 & 0xFFFFFFull) >> ix.hash_tag_bits;
+          const uint64_t diff2 = (r0 ^ text2) & cmask;
+          usable = usable && run2 > (uint64_t)rem && pos2 >= (uint64_t)rem && (diff != 0 || diff2 != 0);
+          if (diff != 0 && diff2 == 0) { pos = pos2; run = run2; diff = 0; }
+        }
+        if (usable) {
           const uint32_t s19 = (uint32_t)((pos - rem) % kPosPerLine);
           if (rem > 32u + 128u - s19) {
             // the slot's text and the window leave a gap: the general kernels

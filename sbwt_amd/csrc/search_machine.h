@@ -671,8 +671,9 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
       for (int k = 0; k < 4; ++k) {
         const uint32_t tag_k = quad_bcast(tag, k);
         const uint32_t q_lo = (uint32_t)hq[k], q_hi = (uint32_t)(hq[k] >> 32);
-        const bool hit = hwant[k] && q_hi != 0xFFFFFFFFu && ((q_lo ^ tag_k) & tmask) == 0;
-        // at most one slot of a bucket carries the tag: OR the masked slot over the quad
+        // (twin slots, device_layout.h, are the fast passes' business: here their prefix reads as not in the table)
+        const bool hit = hwant[k] && !(q_hi >> 31) && ((q_lo ^ tag_k) & tmask) == 0;
+        // at most one such slot of a bucket carries the tag: OR the masked slot over the quad
         uint32_t v0 = hit ? q_lo : 0u, v1 = hit ? q_hi : 0u, any = hit ? 1u : 0u;
         v0 |= quad_swap1(v0); v1 |= quad_swap1(v1); any |= quad_swap1(any);
         v0 |= quad_swap2(v0); v1 |= quad_swap2(v1); any |= quad_swap2(any);

@@ -54,13 +54,14 @@ struct SettleArgs {
 // who asks.  s_bkt: kBktLds uint4 of LDS owned by this wave (a round's 64 slots, then one slot of padding: the four
 // lanes of a quad read their buckets 1040 bytes apart, in different banks).
 // slot / text: the position word and the 32 bases behind the prefix; slot stays ~0 when the prefix is not there.
+// slot2 / text2: the other slot of the bucket with the same tag (twins, device_layout.h), else ~0.
 // absent: the prefix is in none of the buckets looked at and the last of them has a free slot -- it never came by when
 // the table was built (slots are never emptied), which on a hash_complete index means it occurs nowhere.
 // lines += the 128-byte lines of the table this lane's lookup touched (two buckets a line).
 constexpr uint32_t kBktRound = 65, kBktLds = 4 * kBktRound;
 __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4* __restrict__ tab, uint64_t bucket, uint32_t tag,
                                               uint32_t tmask, bool look, uint32_t lane, uint4* s_bkt, uint64_t& slot, uint64_t& text,
-                                              bool& absent, uint32_t& lines) {
+                                              uint64_t& slot2, uint64_t& text2, bool& absent, uint32_t& lines) {
   const uint32_t sub = lane & 3u;
   bool again = false;
 #pragma unroll 1
@@ -91,7 +92,9 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
         const uint4 e = im[q];
         const bool used = e.y != 0xFFFFFFFFu;
         free_slot = free_slot || !used;
-        if (used && ((e.x ^ tag) & tmask) == 0) {  // at most one slot of the group carries the tag
+        if (used && ((e.x ^ tag) & tmask) == 0) {  // one slot of the group carries the tag, or two twins
+          slot2 = slot;
+          text2 = text;
           slot = u64_of(e.x, e.y);
           text = u64_of(e.z, e.w);
           found = true;
@@ -183,13 +186,16 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     const uint64_t bucket = look ? __umul64hi(vv << (64u - 2u * H), ix.hash_buckets) : 0ull;
     const uint32_t tag = (uint32_t)vv & tmask;
     if (look) ++looked;
-    uint64_t slot = ~0ull, text = 0;
+    uint64_t slot = ~0ull, text = 0, slot2 = ~0ull, text2 = 0;
     bool absent = false;
-    settle_lookup(ix, tab, bucket, tag, tmask, look, lane, s_bkt, slot, text, absent, lines_n);
+    settle_lookup(ix, tab, bucket, tag, tmask, look, lane, s_bkt, slot, text, slot2, text2, absent, lines_n);
     bool missed = false;  // looked up and not in the table as a located prefix: the general kernels need not look again
     if (look) {
-      const uint64_t pos = slot >> 24, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
-      missed = slot == ~0ull || run == 0;  // (run 0: a marker -- the prefix occurs, on several rows or on one not located)
+      uint64_t pos = (slot >> 24) & kHashPosMask;
+      const uint64_t run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
+      const bool twin = slot != ~0ull && (slot & kHashTwin) != 0;
+      // (run 0: a marker -- the prefix occurs, on several rows or on one not located; so does a twin without its partner)
+      missed = slot == ~0ull || run == 0 || (twin && (slot2 == ~0ull || !(slot2 & kHashTwin)));
       if (slot == ~0ull && absent && ix.hash_complete) {
         // the first H bases occur nowhere in the text: the upstream search ends on an empty interval (searcher.hpp:406)
         e1 = (uint64_t)R_NOSA << 56;
@@ -197,11 +203,20 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
         ++absent_n;
       } else if (!missed) {
         ++found_n;
-        if (run > (uint64_t)rem && pos >= (uint64_t)rem) {
-          // bases H .. L-1 of the read against the text behind the prefix (search_machine.h, S_CMP: same orientation)
-          uint64_t r0, r1;
-          sm_funnel128(w_lo, w_hi, 0, 0, H, r0, r1);
-          const uint64_t diff = (r0 ^ text) & (rem < 32u ? (1ull << (2 * rem)) - 1ull : ~0ull);
+        // bases H .. L-1 of the read against the text behind the prefix (search_machine.h, S_CMP: same orientation)
+        uint64_t r0, r1;
+        sm_funnel128(w_lo, w_hi, 0, 0, H, r0, r1);
+        const uint64_t cmask = rem < 32u ? (1ull << (2 * rem)) - 1ull : ~0ull;
+        uint64_t diff = (r0 ^ text) & cmask;
+        bool usable = run > (uint64_t)rem && pos >= (uint64_t)rem;
+        if (twin) {
+          // two rows hold the prefix: the one whose text the read goes on with is the row the search ends on, alone
+          const uint64_t pos2 = (slot2 >> 24) & kHashPosMask, run2 = (slot2 & 0xFFFFFFull) >> ix.hash_tag_bits;
+          const uint64_t diff2 = (r0 ^ text2) & cmask;
+          usable = usable && run2 > (uint64_t)rem && pos2 >= (uint64_t)rem && (diff != 0 || diff2 != 0);  // (both: two hits, not here)
+          if (diff != 0 && diff2 == 0) { pos = pos2; diff = 0; }
+        }
+        if (usable) {
           uint32_t meta = R_NOSA;
           uint64_t payload = 0;
           uint32_t chr_id = 0;
