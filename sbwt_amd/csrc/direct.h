@@ -169,10 +169,16 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     if (need_mask) {
       const uintptr_t lp = reinterpret_cast<uintptr_t>(ix.pos_lines + line);
       const uint32_t lp_lo = (uint32_t)lp, lp_hi = (uint32_t)(lp >> 32);
+      // Load k brings the lines of reads 8k .. 8k+7, eight lanes a line, to s_img[64k ..): read j finds its line at
+      // s_img[8j .. 8j+8).  WHICH piece a lane fetches is swizzled by its read: piece q of read j lies at 8j + (q ^ f(j)),
+      // f(j) = 2 (j/8 mod 4) + (j/2 mod 2), so that the sixteen lanes ds_read_b128 serves in one LDS cycle (lanes 0-3,
+      // 12-15, 20-27 ...) read sixteen different 16-byte slots of the 256-byte bank row when every lane reads piece q of
+      // its own line (unswizzled they hit two slots, eight lanes each: SQ_LDS_BANK_CONFLICT was half of the LDS cycles)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int src = 8 * k + (int)(lane >> 3);
-        const uintptr_t q = u64_of((uint32_t)__shfl((int)lp_lo, src), (uint32_t)__shfl((int)lp_hi, src)) + 16u * (lane & 7u);
+        const uint32_t fk = 2u * ((uint32_t)k & 3u) | ((lane >> 4) & 1u);  // f(src)
+        const uintptr_t q = u64_of((uint32_t)__shfl((int)lp_lo, src), (uint32_t)__shfl((int)lp_hi, src)) + 16u * ((lane & 7u) ^ fk);
         if ((need_mask >> src) & 1ull)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)q,
                                            (__attribute__((address_space(3))) void*)(s_img + 64 * k), 16, 0, 0);
@@ -183,11 +189,13 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     }
     if (need_line) {
       ++lines_n;
-      const uint4* im = s_img + 64u * (lane >> 3) + 8u * (lane & 7u);  // this read's line
-      const uint4 ta = im[0], tb = im[1];
+      const uint4* im = s_img + 8u * lane;  // this read's line, its pieces swizzled (above)
+      const uint32_t f = ((lane >> 2) & 6u) | ((lane >> 1) & 1u);
+      const uint4 ta = im[f], tb = im[1u ^ f];
       const uint32_t ob = 32u + 5u * slot19;
       const uint32_t* iw = reinterpret_cast<const uint32_t*>(im);
-      const uint64_t rw = u64_of(iw[ob >> 2], iw[(ob >> 2) + 1]);
+      const uint32_t d0 = ob >> 2, d1 = d0 + 1u;  // the two words that hold the 40 bits (d1 <= 31)
+      const uint64_t rw = u64_of(iw[(((d0 >> 2) ^ f) << 2) | (d0 & 3u)], iw[(((d1 >> 2) ^ f) << 2) | (d1 & 3u)]);
       const uint64_t row = (rw >> (8u * (ob & 3u))) & kPosMask;
       // the last nb bases of the read, [j0, L), against the 128-base window from offset o on (search_machine.h, S_CMP);
       // bases [H, j0) -- at most 32 -- were compared with the slot's text above
