@@ -312,6 +312,11 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
   uint16_t* ts = S.ta;
   uint16_t* td = S.tb;
   for (uint32_t k = tid; k < m; k += T) ts[k] = (uint16_t)k;
+  if (!radix && m > 1u) {
+    // the merge passes: both buffers padded with the largest key up to the next power of two
+    const uint32_t padded = 1u << (32 - __clz((int)(m - 1u)));
+    for (uint32_t k = m + tid; k < padded; k += T) S.ka[k] = S.kb[k] = make_ulonglong2(~0ull, ~0ull);
+  }
   team_sync<T>();
   if (radix) {
     uint16_t* const h16 = reinterpret_cast<uint16_t*>(S.kb);  // [256 digits][kWaveRows] counters
@@ -403,40 +408,48 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
     if (in_order) return SortedRows{ts, src};
   }
   for (uint32_t R = 1; R < m; R <<= 1) {  // sorted runs of R elements -> of 2R
-    ulonglong2 e[4];
-    uint32_t et[4], ob[4], olen[4], cnt[4], dbase[4];
-    bool right[4];
+    // (entries m .. 2^k - 1 of both buffers hold the largest key, see above: the run an element is merged with is always
+    // R entries long, and what lies beyond the real ones never goes before anything)
+    uint64_t ex[4], ey[4], ey_cmp[4];
+    uint32_t et[4], ob1[4], cnt[4], dbase[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint32_t x = tid + (uint32_t)kk * T;
-      ob[kk] = 0; olen[kk] = 0; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0; right[kk] = false;
-      e[kk] = make_ulonglong2(0, 0);
+      ob1[kk] = ~0u; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0;
+      ex[kk] = 0; ey[kk] = 0; ey_cmp[kk] = 0;
       if (x < m) {
-        e[kk] = src[x];
+        const ulonglong2 e = src[x];
         et[kk] = ts[x];
         const uint32_t pair_base = x & ~(2u * R - 1u);
-        right[kk] = (x & R) != 0;
-        const uint32_t other = pair_base + (right[kk] ? 0u : R);  // the run this element is merged with
+        const bool right = (x & R) != 0;
+        ob1[kk] = pair_base + (right ? 0u : R) - 1u;  // the run this element is merged with starts at ob1 + 1
         dbase[kk] = pair_base + (x & (R - 1u));
-        if (other < m) { ob[kk] = other; olen[kk] = m - other < R ? m - other : R; }
+        ex[kk] = e.x;
+        ey[kk] = e.y;
+        // elements of the other run that go before this one: those below it, and -- stability -- for an element of the
+        // right run those equal to it too: v <= e  <=>  v < (e.x, e.y + 1) (the low byte of y is the depth code: no carry)
+        ey_cmp[kk] = e.y + (right ? 1ull : 0ull);
       }
     }
-    // elements of the other run that go before this one, by binary lifting: those below it, and -- stability -- for an
-    // element of the right run those equal to it too
-    for (uint32_t step = R; step; step >>= 1) {
+    // binary lifting, the four searches of a thread side by side: four reads in flight, then four comparisons (written
+    // without a branch: one between a read and the next read makes every read wait for the one before it)
+    // (steps R/2 ... 1 find min(count, R - 1); a last look at the entry behind those, "step" 1 again, makes it the count:
+    // no step ever looks beyond the R entries of the run)
+    for (uint32_t steps = R; steps; steps >>= 1) {
+      const uint32_t step = steps > 1u ? steps >> 1 : 1u;
+      ulonglong2 v[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) v[kk] = src[ob1[kk] + cnt[kk] + step];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const uint32_t c = cnt[kk] + step;
-        const bool in = c <= olen[kk];
-        const ulonglong2 v = src[ob[kk] + (in ? c - 1u : 0u)];
-        const bool before = right[kk] ? !key_less(e[kk], v) : key_less(v, e[kk]);
-        if (in && before) cnt[kk] = c;
+        const bool before = (v[kk].x < ex[kk]) | ((v[kk].x == ex[kk]) & (v[kk].y < ey_cmp[kk]));
+        cnt[kk] += before ? step : 0u;
       }
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint32_t x = tid + (uint32_t)kk * T;
-      if (x < m) { dst[dbase[kk] + cnt[kk]] = e[kk]; td[dbase[kk] + cnt[kk]] = (uint16_t)et[kk]; }
+      if (x < m) { dst[dbase[kk] + cnt[kk]] = make_ulonglong2(ex[kk], ey[kk]); td[dbase[kk] + cnt[kk]] = (uint16_t)et[kk]; }
     }
     team_sync<T>();
     const ulonglong2* const s1 = src; src = dst; dst = const_cast<ulonglong2*>(s1);
