@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
                                                         unsigned long long* __restrict__ chain_count) {
   constexpr uint32_t kTeams = 256 / T;
   constexpr uint32_t kCap = kSortMax / kTeams;  // rows, and entries, a team holds
+  static_assert(kCap == 4u * T, "four rows, and four entries, per thread");
   __shared__ __attribute__((aligned(16))) ulonglong2 s_ka[kSortMax], s_kb[kSortMax];
   __shared__ __attribute__((aligned(16))) uint64_t s_pay[kSortMax];
   __shared__ uint16_t s_ord_all[2][kSortMax];
@@ -1144,44 +1145,73 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     uint64_t ev0[4], meta[4];
     uint32_t n_ev[4], len[4];
     bool fail = false;
+    // three rounds of loads, the four rows of a thread side by side in each (no branch between a row's load and the next
+    // row's: the compiler would make every load wait for the one before it): sa_full; then the text window of a row the
+    // text answers for, or the chain_rows / chain_base words of the other rows' blocks; then their chain_tab entries
+    uint64_t e_sa[4];
+    bool live[4], good[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t i = 4u * tid + (uint32_t)kk;
+      live[kk] = i < m;
+      e_sa[kk] = ix.sa_full[live[kk] ? lo + i : lo];
+    }
+    const uint4* a2[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint64_t row = lo + 4u * tid + (uint32_t)kk;
+      const uint64_t p = e_sa[kk] & kPosMask;
+      const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
+      good[kk] = e_sa[kk] != kNoPosition && (e_sa[kk] >> kPosBits) >= need;
+      a2[kk] = good[kk] ? reinterpret_cast<const uint4*>(ix.textrc) + ((m_text - p) >> 6)
+                        : reinterpret_cast<const uint4*>(&ix.blocks2[(live[kk] ? row : lo) >> 6].chain_rows);
+    }
+    uint4 w0[4], w1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { w0[kk] = a2[kk][0]; w1[kk] = a2[kk][1]; }  // (a block's reserved words behind chain_base: in bounds)
+    const uint4* a3[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint64_t row = lo + 4u * tid + (uint32_t)kk;
+      const uint64_t rows = u64_of(w0[kk].x, w0[kk].y), base = u64_of(w0[kk].z, w0[kk].w);
+      const uint32_t o = (uint32_t)(row & 63);
+      const bool have = live[kk] && !good[kk] && ((rows >> o) & 1ull);
+      if (live[kk] && !good[kk] && !have) fail = true;
+      a3[kk] = reinterpret_cast<const uint4*>(ix.chain_tab + (have ? base + (uint64_t)__popcll(rows & below(o)) : 0ull));
+      good[kk] = good[kk] && live[kk];
+      live[kk] = have;  // from here on: the row has a chain_tab entry
+    }
+    uint4 q0[4], q1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { q0[kk] = a3[kk][0]; q1[kk] = a3[kk][1]; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint32_t i = 4u * tid + (uint32_t)kk;
       full[kk] = make_ulonglong2(0, 0);
       ev0[kk] = 0; meta[kk] = 0; n_ev[kk] = 0; len[kk] = 0;
-      if (i >= m) continue;
-      const uint64_t row = lo + i;
-      const uint64_t e = ix.sa_full[row];
-      const uint64_t p = e & kPosMask;
-      const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
-      if (e != kNoPosition && (e >> kPosBits) >= need) {
+      if (good[kk]) {
         // the text is the chain: bases text[p - 1], text[p - 2], ... = 3 - textrc[x0 ..], one event at depth p mod interval
+        const uint64_t p = e_sa[kk] & kPosMask;
         const uint64_t x0 = m_text - p;
-        const uint4* tx = reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6);
-        const uint4 w0 = tx[0], w1 = tx[1];
         uint64_t c0, c1;
-        sm_funnel128(u64_of(w0.x, w0.y), u64_of(w0.z, w0.w), u64_of(w1.x, w1.y), u64_of(w1.z, w1.w), (uint32_t)(x0 & 63), c0, c1);
+        sm_funnel128(u64_of(w0[kk].x, w0[kk].y), u64_of(w0[kk].z, w0[kk].w), u64_of(w1[kk].x, w1[kk].y), u64_of(w1[kk].z, w1[kk].w),
+                     (uint32_t)(x0 & 63), c0, c1);
         const uint32_t ln = p < depth_max ? (uint32_t)p : depth_max;
         full[kk] = prefix_of(make_ulonglong2(rev_bases(~c0), rev_bases(~c1)), ln);
         len[kk] = ln;
-        const uint32_t t = (uint32_t)(p % ix.interval);
         n_ev[kk] = 1;
-        ev0[kk] = ((uint64_t)t << 58) | p;
-      } else {
-        const Block2* b2 = ix.blocks2 + (row >> 6);
-        const uint64_t rows = b2->chain_rows, base = b2->chain_base;
-        const uint32_t o = (uint32_t)(row & 63);
-        if (!((rows >> o) & 1ull)) { fail = true; continue; }
-        const uint4* ce = reinterpret_cast<const uint4*>(ix.chain_tab + base + (uint64_t)__popcll(rows & below(o)));
-        const uint4 q0 = ce[0], q1 = ce[1];
-        full[kk] = make_ulonglong2(u64_of(q0.x, q0.y), u64_of(q0.z, q0.w));
-        meta[kk] = u64_of(q1.x, q1.y);
-        ev0[kk] = u64_of(q1.z, q1.w);
+        ev0[kk] = ((uint64_t)(uint32_t)(p % ix.interval) << 58) | p;
+      } else if (live[kk]) {
+        full[kk] = make_ulonglong2(u64_of(q0[kk].x, q0[kk].y), u64_of(q0[kk].z, q0[kk].w));
+        meta[kk] = u64_of(q1[kk].x, q1[kk].y);
+        ev0[kk] = u64_of(q1[kk].z, q1[kk].w);
         n_ev[kk] = (uint32_t)meta[kk] & 0xFFu;
         len[kk] = (uint32_t)(meta[kk] >> 8) & 0xFFu;
       }
-      kb[i] = full[kk];
-      len_of[i] = (uint8_t)len[kk];
+      if (i < m) {
+        kb[i] = full[kk];
+        len_of[i] = (uint8_t)len[kk];
+      }
     }
     if (fail) cnt[0] = 1u;
     team_sync<T>();
@@ -1223,67 +1253,70 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     uint32_t slot = team_excl_scan(n_ev[0] + n_ev[1] + n_ev[2] + n_ev[3], &H);
     const bool failed = cnt[0] != 0 || H > kCap;  // (team-uniform: cnt[0] was written before the sync above)
     if (failed) continue;
-    team_sync<T>();  // every thread is done with kb (the sort may take it over) before anything else is written
-    uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
-    bool wrapped = false;
-    // the filters (push_position, searcher.hpp:504-539) of the rows' first events: the table searches of the four run interleaved
-    uint64_t fpos[4];
-    uint32_t c1[4], n1[4];
-    bool frc[4], fgo[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      fpos[kk] = ev0[kk] & kPosMask;
-      frc[kk] = false;
-      fgo[kk] = n_ev[kk] != 0 && push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
-      if (!fgo[kk]) fpos[kk] = 0;
-    }
-    upper_bound_minus1_x4(t_chr, ix.n_chr, fpos, c1);
-    upper_bound_minus1_x4(t_nk, ix.n_npos, fpos, n1);
-    auto put = [&](uint32_t at, const ulonglong2& fullk, uint64_t ev, bool ok, const sbwt_hit& h) {
-      const uint32_t d = (uint32_t)(ev >> 58);
-      const ulonglong2 pre = prefix_of(fullk, d);
-      const ulonglong2 key = sort_key(pre.x, pre.y, d);
-      uint64_t py = (uint64_t)d << 58;
-      if (ok) {
-        if (h.pos0 > kPosMask) wrapped = true;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
-        py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
-      }
-      ka[at] = key;
-      pay[at] = py;
-      or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y;
-    };
-    uint32_t at[4], max_ev = 0;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      at[kk] = slot;
-      slot += n_ev[kk];
-      max_ev = n_ev[kk] > max_ev ? n_ev[kk] : max_ev;
-      if (n_ev[kk]) {
-        sbwt_hit h;
-        const bool ok = fgo[kk] && push_position_finish(ix, t_chr, t_nk, t_nv, fpos[kk], L, frc[kk], c1[kk], n1[kk], &h);
-        put(at[kk], full[kk], ev0[kk], ok, h);
-      }
-    }
-    // the further events of the chains that have any: the four rows' loads of one round in flight together
-    for (uint32_t j = 1; j < max_ev; ++j) {
-      uint64_t ev[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) ev[kk] = j < n_ev[kk] ? ix.chain_ev[(meta[kk] >> kChainEvOffShift) + j - 1] : 0ull;
+    // ---- the event words of every entry, and its row: written by the thread that holds the row (the further events of a
+    // chain come from chain_ev, eight loads in flight) ...
+    uint16_t* const row_of = acc_of;  // (acc_of is not in use before the sort)
+    {
+      uint32_t at = slot;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t i = 4u * tid + (uint32_t)kk, n = n_ev[kk];
+        if (n) { pay[at] = ev0[kk]; row_of[at] = (uint16_t)i; }
+        if (n > 1u) {
+          const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
+          for (uint32_t j = 1; j < n; j += 8) {
+            uint64_t t8[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) t8[q] = evs[(j + q < n ? j + q : n - 1u) - 1u];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q)
+              if (j + q < n) { pay[at + j + q] = t8[q]; row_of[at + j + q] = (uint16_t)i; }
+          }
+        }
+        at += n;
+      }
+    }
+    team_sync<T>();
+    // ... and turned into keys and filtered hits by ALL threads, four entries each (H <= kCap = 4 T): a row with many
+    // events costs its thread a few stores above, not a filter run per event.  The filters (push_position,
+    // searcher.hpp:504-539): the table searches of a thread's four entries run interleaved
+    uint64_t or0 = 0, and0 = ~0ull, or1 = 0, and1 = ~0ull;
+    bool wrapped = false;
+    {
+      uint64_t ev[4], fpos[4];
+      ulonglong2 fullk[4];
+      uint32_t c1[4], n1[4];
+      bool frc[4], fgo[4], have[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t k = tid + (uint32_t)kk * T;
+        have[kk] = k < H;
+        ev[kk] = have[kk] ? pay[k] : 0ull;
+        fullk[kk] = kb[have[kk] ? row_of[k] : 0u];
         fpos[kk] = ev[kk] & kPosMask;
         frc[kk] = false;
-        fgo[kk] = j < n_ev[kk] && push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
+        fgo[kk] = have[kk] && push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
         if (!fgo[kk]) fpos[kk] = 0;
       }
       upper_bound_minus1_x4(t_chr, ix.n_chr, fpos, c1);
       upper_bound_minus1_x4(t_nk, ix.n_npos, fpos, n1);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if (j >= n_ev[kk]) continue;
+        if (!have[kk]) continue;
+        const uint32_t k = tid + (uint32_t)kk * T;
         sbwt_hit h;
         const bool ok = fgo[kk] && push_position_finish(ix, t_chr, t_nk, t_nv, fpos[kk], L, frc[kk], c1[kk], n1[kk], &h);
-        put(at[kk] + j, full[kk], ev[kk], ok, h);
+        const uint32_t d = (uint32_t)(ev[kk] >> 58);
+        const ulonglong2 pre = prefix_of(fullk[kk], d);
+        const ulonglong2 key = sort_key(pre.x, pre.y, d);
+        uint64_t py = (uint64_t)d << 58;
+        if (ok) {
+          if (h.pos0 > kPosMask) wrapped = true;  // (an upstream-accepted wrapped position: k_multi writes whole hits)
+          py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+        }
+        ka[k] = key;
+        pay[k] = py;
+        or0 |= key.x; and0 &= key.x; or1 |= key.y; and1 &= key.y;
       }
     }
     if (wrapped) cnt[0] = 1u;
