@@ -1253,26 +1253,17 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     uint32_t slot = team_excl_scan(n_ev[0] + n_ev[1] + n_ev[2] + n_ev[3], &H);
     const bool failed = cnt[0] != 0 || H > kCap;  // (team-uniform: cnt[0] was written before the sync above)
     if (failed) continue;
-    // ---- the event words of every entry, and its row: written by the thread that holds the row (the further events of a
-    // chain come from chain_ev, eight loads in flight) ...
+    // ---- the event word of every entry, and its row: written by the thread that holds the row ...
     uint16_t* const row_of = acc_of;  // (acc_of is not in use before the sort)
+    constexpr uint64_t kEvIndirect = 1ull << 57;  // (an event word is depth << 58 | position: bit 57 is free)
     {
       uint32_t at = slot;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const uint32_t i = 4u * tid + (uint32_t)kk, n = n_ev[kk];
         if (n) { pay[at] = ev0[kk]; row_of[at] = (uint16_t)i; }
-        if (n > 1u) {
-          const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
-          for (uint32_t j = 1; j < n; j += 8) {
-            uint64_t t8[8];
-#pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) t8[q] = evs[(j + q < n ? j + q : n - 1u) - 1u];
-#pragma unroll
-            for (uint32_t q = 0; q < 8; ++q)
-              if (j + q < n) { pay[at + j + q] = t8[q]; row_of[at + j + q] = (uint16_t)i; }
-          }
-        }
+        // (a further event: where it lies in chain_ev; whoever gets the entry below fetches it)
+        for (uint32_t j = 1; j < n; ++j) { pay[at + j] = kEvIndirect | ((meta[kk] >> kChainEvOffShift) + j - 1u); row_of[at + j] = (uint16_t)i; }
         at += n;
       }
     }
@@ -1293,6 +1284,16 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
         have[kk] = k < H;
         ev[kk] = have[kk] ? pay[k] : 0ull;
         fullk[kk] = kb[have[kk] ? row_of[k] : 0u];
+      }
+      {
+        uint64_t fetched[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fetched[kk] = ix.chain_ev[(ev[kk] & kEvIndirect) ? ev[kk] & (kEvIndirect - 1ull) : 0ull];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ev[kk] = (ev[kk] & kEvIndirect) ? fetched[kk] : ev[kk];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
         fpos[kk] = ev[kk] & kPosMask;
         frc[kk] = false;
         fgo[kk] = have[kk] && push_position_orient(ix, fpos[kk], L, a.strand, frc[kk]);
