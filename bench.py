@@ -590,8 +590,8 @@ class Run:
              "parity_vs_oracle": parity["identical"] if parity else None,
              "reads_checked": parity["reads_checked"] if parity else 0}
         if self.multi:     # locate-heavy workloads
-            e.update({"multi_hit_reads": self.multi, "list_hits": int(self.list_hits), "multi_locate_ms": round(A["multi_ms"], 3),
-                      "rows_located": int(st[12]), "reads_off_the_text": int(st[3]), "of_which_from_chain_tab": int(st[11])})
+            e.update({"multi_hit_reads": self.multi, "list_hits": int(self.list_hits),
+                      "rows_located": int(st[12]), "reads_off_the_text": int(st[3]), "from_chain_tab": int(st[11])})
         if short is None:
             e["workload"] = workload
         return e
@@ -722,7 +722,7 @@ def strong_scaling(args, torch, dev, sb, dist, rank, world):
     t0 = time.time()
     packed = torch.empty((mine, wpr), dtype=torch.int32, device=dev)
     lens = torch.empty((mine,), dtype=torch.int32, device=dev)
-    gen = 1 << 24
+    gen = 1 << 21   # (make_reads needs about 1.5 KB of temporaries per 100-bp read: 3 GB a piece, next to a share of up to 29 GB)
     for c in range(a // gen, (b - 1) // gen + 1 if mine else 0):
         # piece c of the whole input (reads [c * gen, (c + 1) * gen)) is generated from seed 1000 + c whoever needs a
         # part of it: read i of the input is the same read whatever the number of ranks
@@ -733,6 +733,7 @@ def strong_scaling(args, torch, dev, sb, dist, rank, world):
         del p, l
     wl.drop_genome()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()   # (the ctx below allocates through the library, not through torch's cache)
     t_reads = time.time() - t0
     ctx = sb.Context(wl.ix, chunk)
     outs = [torch.empty(chunk * 16, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -917,8 +918,7 @@ def main():
             t = json.load(open(tpath))
             if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9 and plain \
                     and not args.rank_path and t.get("kernel") == dom_kernel:
-                stored = {"source": "profiles/%s/traffic_%s.json (rocprofv3 --pmc passes of the same command on another box of this "
-                                    "pool; NOT measured in this run)" % (tdir, args.layout),
+                stored = {"source": "profiles/%s/traffic_%s.json: PMC passes of the same command on another box, NOT this run" % (tdir, args.layout),
                           "traffic_GB_per_launch": t.get("traffic_GB_per_launch"),
                           "hbm_requests_per_launch": t.get("hbm_requests_per_launch")}
     roofline = {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -1067,7 +1067,7 @@ def main():
             try:
                 out = fn()
                 for e in (out if isinstance(out, list) else [out]):
-                    e["took_s"] = round(time.time() - t1, 1)
+                    e["s"] = round(time.time() - t1, 1)     # wall time of this entry, builds and checks included
                     configs.append(e)
             except Exception as e:   # a side line must never cost the headline
                 configs.append({"name": name, "error": "%s: %s" % (type(e).__name__, e)})
@@ -1075,6 +1075,7 @@ def main():
 
         steps_side = 3
         w3 = "configs[2], SA intervals reported"
+        wl_n = int(wl.info.n)      # (entries on an index of another size say so)
         guarded("config3_intervals", lambda: side_case(torch, dev, sbwt_amd, olib, wl, "config3_intervals", w3, n_reads, L,
                                                        ["compact", "plain"], steps_side, cores, packed=packed, lens=lens))
         del packed, lens
@@ -1094,8 +1095,8 @@ def main():
                     out = side_case(torch, dev, sbwt_amd, olib, w2, name, workload, n, rl, layouts, steps_side, cores,
                                     min_len=min_len, probe_n=probe_n)
                     for e in out:
-                        e["index_suffixes"] = int(w2.info.n)
-                        e["index_build_s"] = round(w2.t_index, 1)
+                        if int(w2.info.n) != int(wl_n):
+                            e["index_suffixes"] = int(w2.info.n)
                     return out
                 finally:
                     w2.close()
