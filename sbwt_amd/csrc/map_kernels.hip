@@ -521,6 +521,8 @@ static int pass_search(const sbwt_index* ix, const MapWork& w, const uint32_t* d
     ms.shared_count = &w.d_ctr->shared_count;
     ms.bfs_count = &w.d_ctr->bfs_count;
     ms.rows_count = &w.d_ctr->rows_located;
+    static const uint32_t no_segments = getenv("SBWT_NO_SEGMENTS") ? (uint32_t)atoi(getenv("SBWT_NO_SEGMENTS")) : 0u;  // (read once per process; 1: none, 2: no segments of 8)
+    ms.no_segments = no_segments;
     ms.grp.keys = nullptr;
     ms.grp.leader = nullptr;
     ms.grp.mask = 0;

@@ -16,6 +16,7 @@
 // kSortMax rows, or on an index sampled wider than 64 go to the depth-first kernel (k_multi) instead.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/sbwt_amd.h"
@@ -96,6 +97,7 @@ struct MultiSortArgs {
   unsigned long long* shared_count;      // reads whose record points at their leader's list (k_multi_share)
   unsigned long long* bfs_count;         // reads of the depth-first queue that k_multi_bfs located
   unsigned long long* rows_count;        // raw rows of the reads the locate kernels located themselves (measurement: a shared list counts once)
+  uint32_t no_segments;                  // wave teams take one read at a time whatever its size (SBWT_NO_SEGMENTS: measurement and tests)
 };
 
 // Turns the per-wave totals of k_search_sm into global offsets: exclusive prefix sums of the hit slots and of the
@@ -263,6 +265,64 @@ __device__ __forceinline__ ulonglong2 sorted_key(const SortedRows& R, const Sort
   return R.keys ? R.keys[k] : S.ka[R.ord[k]];
 }
 
+// The merge passes of team_sort_rows: sorted runs of 1, 2, 4 ... entries of src merged pairwise until the runs hold r_end
+// entries (r_end >= m: the whole array; smaller: every aligned segment of r_end entries for itself).  ts / td: the entry
+// indices, moved along with the keys.  Entries m .. (next power of two) - 1 of BOTH key buffers hold the largest key; no
+// entry that is merged itself (x < m) has an all-ones second word.
+template <int T>
+__device__ __forceinline__ SortedRows merge_by_rank(const ulonglong2* src, ulonglong2* dst, uint16_t* ts, uint16_t* td, uint32_t m,
+                                                    uint32_t r_end, uint32_t tid) {
+  for (uint32_t R = 1; R < m && R < r_end; R <<= 1) {  // sorted runs of R elements -> of 2R
+    // (entries m .. 2^k - 1 of both buffers hold the largest key, see above: the run an element is merged with is always
+    // R entries long, and what lies beyond the real ones never goes before anything)
+    uint64_t ex[4], ey[4], ey_cmp[4];
+    uint32_t et[4], ob1[4], cnt[4], dbase[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t x = tid + (uint32_t)kk * T;
+      ob1[kk] = ~0u; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0;
+      ex[kk] = 0; ey[kk] = 0; ey_cmp[kk] = 0;
+      if (x < m) {
+        const ulonglong2 e = src[x];
+        et[kk] = ts[x];
+        const uint32_t pair_base = x & ~(2u * R - 1u);
+        const bool right = (x & R) != 0;
+        ob1[kk] = pair_base + (right ? 0u : R) - 1u;  // the run this element is merged with starts at ob1 + 1
+        dbase[kk] = pair_base + (x & (R - 1u));
+        ex[kk] = e.x;
+        ey[kk] = e.y;
+        // elements of the other run that go before this one: those below it, and -- stability -- for an element of the
+        // right run those equal to it too: v <= e  <=>  v < (e.x, e.y + 1) (the low byte of y is the depth code: no carry)
+        ey_cmp[kk] = e.y + (right ? 1ull : 0ull);
+      }
+    }
+    // binary lifting, the four searches of a thread side by side: four reads in flight, then four comparisons (written
+    // without a branch: one between a read and the next read makes every read wait for the one before it)
+    // (steps R/2 ... 1 find min(count, R - 1); a last look at the entry behind those, "step" 1 again, makes it the count:
+    // no step ever looks beyond the R entries of the run)
+    for (uint32_t steps = R; steps; steps >>= 1) {
+      const uint32_t step = steps > 1u ? steps >> 1 : 1u;
+      ulonglong2 v[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) v[kk] = src[ob1[kk] + cnt[kk] + step];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bool before = (v[kk].x < ex[kk]) | ((v[kk].x == ex[kk]) & (v[kk].y < ey_cmp[kk]));
+        cnt[kk] += before ? step : 0u;
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t x = tid + (uint32_t)kk * T;
+      if (x < m) { dst[dbase[kk] + cnt[kk]] = make_ulonglong2(ex[kk], ey[kk]); td[dbase[kk] + cnt[kk]] = (uint16_t)et[kk]; }
+    }
+    team_sync<T>();
+    const ulonglong2* const s1 = src; src = dst; dst = const_cast<ulonglong2*>(s1);
+    uint16_t* const t1 = ts; ts = td; td = t1;
+  }
+  return SortedRows{ts, src};
+}
+
 // Puts the m entries of one read in emission order: keys ascending, equal keys in entry order.  or0 .. and1: OR and AND
 // of the key words over the calling thread's entries.  Returns the order (SortedRows); ka and kb do not keep their
 // contents.  Every thread of the team calls it.
@@ -407,55 +467,7 @@ __device__ __forceinline__ SortedRows team_sort_rows(const SortLds& S, uint32_t 
     }
     if (in_order) return SortedRows{ts, src};
   }
-  for (uint32_t R = 1; R < m; R <<= 1) {  // sorted runs of R elements -> of 2R
-    // (entries m .. 2^k - 1 of both buffers hold the largest key, see above: the run an element is merged with is always
-    // R entries long, and what lies beyond the real ones never goes before anything)
-    uint64_t ex[4], ey[4], ey_cmp[4];
-    uint32_t et[4], ob1[4], cnt[4], dbase[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t x = tid + (uint32_t)kk * T;
-      ob1[kk] = ~0u; cnt[kk] = 0; dbase[kk] = 0; et[kk] = 0;
-      ex[kk] = 0; ey[kk] = 0; ey_cmp[kk] = 0;
-      if (x < m) {
-        const ulonglong2 e = src[x];
-        et[kk] = ts[x];
-        const uint32_t pair_base = x & ~(2u * R - 1u);
-        const bool right = (x & R) != 0;
-        ob1[kk] = pair_base + (right ? 0u : R) - 1u;  // the run this element is merged with starts at ob1 + 1
-        dbase[kk] = pair_base + (x & (R - 1u));
-        ex[kk] = e.x;
-        ey[kk] = e.y;
-        // elements of the other run that go before this one: those below it, and -- stability -- for an element of the
-        // right run those equal to it too: v <= e  <=>  v < (e.x, e.y + 1) (the low byte of y is the depth code: no carry)
-        ey_cmp[kk] = e.y + (right ? 1ull : 0ull);
-      }
-    }
-    // binary lifting, the four searches of a thread side by side: four reads in flight, then four comparisons (written
-    // without a branch: one between a read and the next read makes every read wait for the one before it)
-    // (steps R/2 ... 1 find min(count, R - 1); a last look at the entry behind those, "step" 1 again, makes it the count:
-    // no step ever looks beyond the R entries of the run)
-    for (uint32_t steps = R; steps; steps >>= 1) {
-      const uint32_t step = steps > 1u ? steps >> 1 : 1u;
-      ulonglong2 v[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) v[kk] = src[ob1[kk] + cnt[kk] + step];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bool before = (v[kk].x < ex[kk]) | ((v[kk].x == ex[kk]) & (v[kk].y < ey_cmp[kk]));
-        cnt[kk] += before ? step : 0u;
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t x = tid + (uint32_t)kk * T;
-      if (x < m) { dst[dbase[kk] + cnt[kk]] = make_ulonglong2(ex[kk], ey[kk]); td[dbase[kk] + cnt[kk]] = (uint16_t)et[kk]; }
-    }
-    team_sync<T>();
-    const ulonglong2* const s1 = src; src = dst; dst = const_cast<ulonglong2*>(s1);
-    uint16_t* const t1 = ts; ts = td; td = t1;
-  }
-  return SortedRows{ts, src};
+  return merge_by_rank<T>(src, dst, ts, td, m, m, tid);
 }
 
 // -DSBWT_PHASE_CLOCKS: thread 0 of every team adds the clocks each phase of a read took to g_multi_phase[] (a
@@ -818,6 +830,10 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   __shared__ uint32_t s_bad_all[4];
   __shared__ uint16_t s_ord_all[2][kSortMax];
   __shared__ uint64_t s_red_all[4][4];          // OR / AND of the key words over a wave's rows
+  // wave teams, several small reads at a time (seg_pass below): per segment the read's interval, slots, length
+  constexpr uint32_t kSegMax = 32;
+  __shared__ uint64_t s_seg_lo_all[4][kSegMax], s_seg_first_all[4][kSegMax];
+  __shared__ uint32_t s_seg_m_all[4][kSegMax], s_seg_len_all[4][kSegMax], s_seg_bad_all[4][kSegMax];
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];  // (n_chr + 2 n_npos) words when a.lds_tables
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
   // push_position tables: LDS copies when they fit
@@ -846,7 +862,146 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   const SortLds sort_lds{ka, s_kb + team * kCap, s_ord_all[0] + team * kCap, s_ord_all[1] + team * kCap, s_red_all, s_scan_all};
   const uint64_t m_text = ix.n - 1;
   const bool no_sort_path = ix.interval > 64 || ix.n_chr > 0xFFFFu;  // payload fields too narrow: depth-first walk
-  unsigned long long rows_done = 0;  // (thread 0 of a team)
+  unsigned long long rows_done = 0;  // (thread 0 of a team; seg_pass: the first lane of a segment)
+  // ---- wave teams: SEVERAL small reads at a time.  Most multi-hit reads have a handful of rows (on the repeat-rich bench
+  // genome 960,000 of the 1.34 x 10^6 reads of up to 256 rows have at most 8): a wave per read spends its time on the
+  // latency of three dependent accesses with a few lanes at work.  The 256 entries of a wave team are cut into segments of
+  // kS entries, a read each (32 reads of <= 8 rows, or 4 of <= 64): the same loads, filters and keys for all of them at once,
+  // unused entries padded with the largest key, and the merge passes stopped at runs of kS entries sort every segment for itself.
+  uint64_t* const seg_lo = s_seg_lo_all[team];
+  uint64_t* const seg_first = s_seg_first_all[team];
+  uint32_t* const seg_m = s_seg_m_all[team];
+  uint32_t* const seg_len = s_seg_len_all[team];
+  uint32_t* const seg_bad = s_seg_bad_all[team];
+  auto seg_pass = [&](auto seg_size, const uint32_t* lst, uint32_t nseg, const WaveInfo& wi) {
+    constexpr uint32_t kS = decltype(seg_size)::value;
+    static_assert(256u / kS <= kSegMax, "segment descriptors");
+    if (lane < nseg) {
+      const uint32_t r = lst[lane];
+      const MultiRead mr = rio_load(a.io, r);
+      seg_lo[lane] = mr.lo;
+      seg_m[lane] = (uint32_t)(mr.hi - mr.lo);
+      seg_first[lane] = mr.first_hit + a.multi_base + wi.slots;  // wave-relative until now
+      seg_len[lane] = a.lens[r];
+      seg_bad[lane] = 0;
+    }
+    team_sync<T>();
+    uint64_t e4[4];
+    uint32_t len4[4];
+    bool live[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t x = lane + 64u * (uint32_t)kk, g = x / kS, i = x % kS;
+      live[kk] = g < nseg && i < seg_m[g];
+      len4[kk] = g < nseg ? seg_len[g] : 0u;
+      e4[kk] = live[kk] ? ix.sa_full[seg_lo[g] + i] : kNoPosition;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t g = (lane + 64u * (uint32_t)kk) / kS;
+      const uint64_t p = e4[kk] & kPosMask;
+      // a row the text does not answer for: its read goes to k_multi_chain / the walk
+      if (live[kk] && (e4[kk] == kNoPosition || (e4[kk] >> kPosBits) < (p + 1 < ix.interval ? p + 1 : ix.interval))) seg_bad[g] = 1u;
+    }
+    team_sync<T>();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t g = (lane + 64u * (uint32_t)kk) / kS;
+      live[kk] = live[kk] && !seg_bad[g];
+    }
+    // the text windows, pair-cooperative (as below)
+    uint4 tw[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint64_t p = e4[kk] & kPosMask;
+      const uint64_t x0 = !live[kk] || p > m_text ? 0 : m_text - p;
+      const uintptr_t tx = reinterpret_cast<uintptr_t>(reinterpret_cast<const uint4*>(ix.textrc) + (x0 >> 6));
+      const uint32_t tx_lo = (uint32_t)tx, tx_hi = (uint32_t)(tx >> 32);
+      const uintptr_t t0 = u64_of(pair_bcast<0>(tx_lo), pair_bcast<0>(tx_hi)), t1 = u64_of(pair_bcast<1>(tx_lo), pair_bcast<1>(tx_hi));
+      const uint4 r0 = reinterpret_cast<const uint4*>(t0)[lane & 1u];
+      const uint4 r1 = reinterpret_cast<const uint4*>(t1)[lane & 1u];
+      const uint4 s0 = make_uint4(quad_swap1(r0.x), quad_swap1(r0.y), quad_swap1(r0.z), quad_swap1(r0.w));
+      const uint4 s1 = make_uint4(quad_swap1(r1.x), quad_swap1(r1.y), quad_swap1(r1.z), quad_swap1(r1.w));
+      tw[kk][0] = (lane & 1u) ? s1 : r0;
+      tw[kk][1] = (lane & 1u) ? r1 : s0;
+    }
+    uint64_t fpos[4] = {0, 0, 0, 0};
+    uint32_t c1[4], n1[4];
+    bool frc[4], fgo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      frc[kk] = false;
+      fgo[kk] = false;
+      if (live[kk]) {
+        fpos[kk] = e4[kk] & kPosMask;
+        fgo[kk] = push_position_orient(ix, fpos[kk], len4[kk], a.strand, frc[kk]);
+        if (!fgo[kk]) fpos[kk] = 0;
+      }
+    }
+    upper_bound_minus1_x4(t_chr, ix.n_chr, fpos, c1);
+    upper_bound_minus1_x4(t_nk, ix.n_npos, fpos, n1);
+    const bool pow2 = (ix.interval & (ix.interval - 1u)) == 0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t x = lane + 64u * (uint32_t)kk, g = x / kS;
+      // (an unused entry: above every key of a row; not all ones, because these entries ARE merged -- an element of a right
+      // run is compared through y + 1, merge_by_rank)
+      ulonglong2 key = make_ulonglong2(~0ull, ~0ull - 1ull);
+      uint64_t py = 63ull << 58;
+      if (live[kk]) {
+        const uint64_t p = e4[kk] & kPosMask;
+        const uint32_t t = pow2 ? (uint32_t)p & (ix.interval - 1u) : (uint32_t)(p % ix.interval);
+        const uint64_t x0 = m_text - p;
+        sbwt_hit h;
+        const bool ok = fgo[kk] && push_position_finish(ix, t_chr, t_nk, t_nv, fpos[kk], len4[kk], frc[kk], c1[kk], n1[kk], &h);
+        uint64_t c0, cc1;
+        sm_funnel128(u64_of(tw[kk][0].x, tw[kk][0].y), u64_of(tw[kk][0].z, tw[kk][0].w), u64_of(tw[kk][1].x, tw[kk][1].y),
+                     u64_of(tw[kk][1].z, tw[kk][1].w), (uint32_t)(x0 & 63), c0, cc1);
+        c0 = ~c0;
+        cc1 = ~cc1;
+        if (t < 32u) { c0 &= t ? ((1ull << (2 * t)) - 1ull) : 0ull; cc1 = 0; }
+        else if (t < 64u) cc1 &= t > 32u ? ((1ull << (2 * (t - 32u))) - 1ull) : 0ull;
+        key = sort_key(rev_bases(c0), rev_bases(cc1), t);
+        py = ((uint64_t)t << 58);
+        if (ok && h.pos0 > kPosMask) seg_bad[g] = 1u;  // (an upstream-accepted wrapped position: the depth-first kernel writes whole hits)
+        if (ok) py |= kPayOk | (h.pos0 & kPosMask) | ((uint64_t)h.chr_id << kPosBits) | ((uint64_t)(h.is_rc & 1u) << 56);
+      }
+      ka[x] = key;
+      pay[x] = py;
+      sort_lds.ta[x] = (uint16_t)x;
+    }
+    team_sync<T>();
+    const SortedRows sorted = merge_by_rank<T>(sort_lds.ka, sort_lds.kb, sort_lds.ta, sort_lds.tb, 256u, kS, lane);
+    // every segment's rows in emission order: compact those that passed the filters, write
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t k = lane + 64u * (uint32_t)kk, g = k / kS, i = k % kS;
+      const bool seg = g < nseg, bad = seg && seg_bad[g] != 0;
+      uint64_t py = 0;
+      if (seg && !bad) py = pay[sorted.ord[k]];
+      const bool ok = (py & kPayOk) != 0;
+      const uint64_t bal = __ballot(ok);
+      const uint64_t mine_bits = kS == 64 ? bal : (bal >> (lane & ~(kS - 1u))) & ((1ull << (kS & 63u)) - 1ull);
+      if (ok) {
+        sbwt_hit h;
+        h.pos0 = py & kPosMask;
+        h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
+        h.is_rc = (uint32_t)(py >> 56) & 1u;
+        a.hits[seg_first[g] + (uint32_t)__popcll(mine_bits & ((1ull << i) - 1ull))] = h;
+      }
+      if (seg && i == 0) {
+        const uint32_t r = lst[g];
+        if (bad) {
+          rio_store_multi(a.io, r, seg_first[g], false, 0, 0u);
+          a.dfs_queue[atomicAdd(a.dfs_count, 1ull)] = r;
+        } else {
+          rio_store_multi(a.io, r, seg_first[g], true, (int32_t)__popcll(mine_bits), 0u);
+          rows_done += seg_m[g];
+        }
+      }
+    }
+    team_sync<T>();
+  };
   // teams stride over the waves of the search kernel; each wave queued its reads at queue[w * chunk ..)
   for (uint32_t w = blockIdx.x * kTeams + team; w < a.n_waves; w += gridDim.x * kTeams) {
     const WaveInfo wi = a.wave_info[w];
@@ -854,17 +1009,27 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
       // the team looks at T queue entries at once and keeps those this launch takes
       uint32_t my_r = 0;
       bool mine = false;
+      uint32_t cls = 2;  // wave teams: 0 = at most 8 rows, 1 = at most 64 (several reads at a time, seg_pass), 2 = one read at a time
       if (q0 + tid < wi.count) {
         my_r = a.queue[(uint64_t)w * a.chunk + q0 + tid];
         const MultiRead mr = rio_load(a.io, my_r);
         const uint64_t m = mr.hi - mr.lo;
         mine = T == 64 ? m <= kCap : m > kSortMax / 4;
         if (mine && a.grp.keys) mine = group_leader(a.grp, my_r, mr.lo, m, a.lens[my_r]) == my_r;
+        if (T == 64 && !no_sort_path && a.no_segments != 1u) cls = m <= 8 && a.no_segments != 2u ? 0u : m <= 64 ? 1u : 2u;
       }
-      uint32_t n_list;
+      uint32_t n_list, n_cls0 = 0, n_cls1 = 0;
       {
         const uint64_t bal = __ballot(mine);
         uint32_t off = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (T == 64) {
+          // the list in the order of the classes
+          const uint64_t lt = (1ull << lane) - 1ull;
+          const uint64_t b0 = __ballot(mine && cls == 0), b1 = __ballot(mine && cls == 1), b2 = __ballot(mine && cls == 2);
+          n_cls0 = (uint32_t)__popcll(b0);
+          n_cls1 = (uint32_t)__popcll(b1);
+          off = cls == 0 ? (uint32_t)__popcll(b0 & lt) : cls == 1 ? n_cls0 + (uint32_t)__popcll(b1 & lt) : n_cls0 + n_cls1 + (uint32_t)__popcll(b2 & lt);
+        }
         if (T == 256) {
           const uint32_t wave = threadIdx.x >> 6;
           __syncthreads();  // the previous batch is done with list and s_scan_all
@@ -879,7 +1044,11 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
       }
       team_sync<T>();
       SBWT_PHASE(0);
-      for (uint32_t li = 0; li < n_list; ++li) {
+      if constexpr (T == 64) {
+        for (uint32_t at = 0; at < n_cls0; at += 32) seg_pass(std::integral_constant<uint32_t, 8>{}, list + at, n_cls0 - at < 32u ? n_cls0 - at : 32u, wi);
+        for (uint32_t at = 0; at < n_cls1; at += 4) seg_pass(std::integral_constant<uint32_t, 64>{}, list + n_cls0 + at, n_cls1 - at < 4u ? n_cls1 - at : 4u, wi);
+      }
+      for (uint32_t li = n_cls0 + n_cls1; li < n_list; ++li) {
         const uint32_t r = list[li];
         MultiRead res = rio_load(a.io, r);
         const uint64_t lo = res.lo, m = res.hi - res.lo;
@@ -1032,7 +1201,8 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
       }
     }
   }
-  if (tid == 0 && rows_done) atomicAdd(a.rows_count, rows_done);
+  for (int d = 32; d > 0; d >>= 1) rows_done += shfl_xor64(rows_done, (uint32_t)d);
+  if (lane == 0 && rows_done) atomicAdd(a.rows_count, rows_done);
 #ifdef SBWT_PHASE_CLOCKS
   team_sync<T>();
   if (tid < 12 && T == 256) atomicAdd(&g_multi_phase[12 + tid], s_phase[team][tid]);
