@@ -621,7 +621,7 @@ def side_case(torch, dev, sb, oracle_lib, wl, name, workload, n_reads, L, layout
                 run.timed(steps, 1)
                 run.decode()
                 par, _ = run.parity(oracle_lib, probe_n, cores) if oracle_lib else (None, None)
-                out.append(run.summary(name, workload, par))
+                out.append(run.summary(name, workload, par, short=True if out else None))   # (the workload: once per name)
             finally:
                 run.close()
     finally:
@@ -681,8 +681,8 @@ def file_path_case(torch, dev, sb, wl, cores, n_reads, L=50):
         ix2.close()
     finally:
         shutil.rmtree(tmpd, ignore_errors=True)
-    return {"name": "index_files", "workload": "the headline's index saved in the upstream file format (%.2f GB t_table.bwt) and "
-            "loaded by sbwt_index_load, %d x %d bp" % (file_gb, n_reads, L), "layout": "compact",
+    return {"name": "index_files", "workload": "the headline's index through upstream-format files (%.2f GB t_table.bwt), sbwt_index_load, %d x %d bp"
+            % (file_gb, n_reads, L), "layout": "compact",
             "index_save_s": round(t_save, 1), "index_load_s": round(t_load, 1),
             "reads_per_s": round(n_reads / (ms_loaded * 1e-3), 1), "device_ms_loaded": round(ms_loaded, 3),
             "device_ms_built": round(ms_built, 3), "index_hbm_GB": round(info2.device_bytes / 1e9, 2),
@@ -966,7 +966,6 @@ def main():
         dt = time.perf_counter() - t1
         del seqs, offsets
         cpu = {"value": round(sample_n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-               "host_cpus": os.cpu_count(),
                "sample": "first %d reads of the same batch, same index (reference-format tables), %d threads; "
                          "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n),
                "note": "about 2x the reference binary per thread (SURVEY.md section 6)"}

@@ -191,10 +191,13 @@ struct MapWork {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // null: the pass is not timed ([3], [4]: around locate kernels launched in a second phase)
   // test knobs (environment variables, read ONCE: when the ctx is made, or -- the entry point without a ctx -- the index)
   bool no_bfs = false, no_chain = false;
+  uint32_t no_segments = 0;  // SBWT_NO_SEGMENTS: 1 = wave teams locate one read at a time, 2 = no segments of 8 entries
   uint32_t ring_width_max = (uint32_t)kRingWidthMax, ring_chr_max = 0xFFFFu;
 };
 
-static void read_pass_knobs(bool* no_bfs, bool* no_chain, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
+static void read_pass_knobs(bool* no_bfs, bool* no_chain, uint32_t* no_segments, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
+  const char* seg = getenv("SBWT_NO_SEGMENTS");
+  *no_segments = seg && *seg ? (uint32_t)strtoul(seg, nullptr, 10) : 0u;
   *no_bfs = getenv("SBWT_NO_BFS") != nullptr;
   *no_chain = getenv("SBWT_NO_CHAIN") != nullptr;
   *ring_width_max = debug_knob("SBWT_DEBUG_RING_WIDTH", (uint32_t)kRingWidthMax);
@@ -268,7 +271,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (!c) return SBWT_ERR_NOMEM;
   c->ix = ix;
   c->max_reads = max_reads;
-  read_pass_knobs(&c->no_bfs, &c->no_chain, &c->ring_width_max, &c->ring_chr_max);
+  read_pass_knobs(&c->no_bfs, &c->no_chain, &c->no_segments, &c->ring_width_max, &c->ring_chr_max);
   c->no_settle = getenv("SBWT_NO_SETTLE") != nullptr;
   c->no_direct = getenv("SBWT_NO_DIRECT") != nullptr;
   c->no_spec = getenv("SBWT_NO_SPECULATIVE_PENDING") != nullptr;
@@ -521,8 +524,7 @@ static int pass_search(const sbwt_index* ix, const MapWork& w, const uint32_t* d
     ms.shared_count = &w.d_ctr->shared_count;
     ms.bfs_count = &w.d_ctr->bfs_count;
     ms.rows_count = &w.d_ctr->rows_located;
-    static const uint32_t no_segments = getenv("SBWT_NO_SEGMENTS") ? (uint32_t)atoi(getenv("SBWT_NO_SEGMENTS")) : 0u;  // (read once per process; 1: none, 2: no segments of 8)
-    ms.no_segments = no_segments;
+    ms.no_segments = w.no_segments;
     ms.grp.keys = nullptr;
     ms.grp.leader = nullptr;
     ms.grp.mask = 0;
@@ -1038,7 +1040,7 @@ int sbwt::finish_index(sbwt_index* ix) {
   ix->plan.sm_lds_bytes = w.sm_lds_bytes;
   ix->plan.sm_ring_bytes = w.sm_ring_bytes;
   ix->plan.sort_lds_bytes = w.sort_lds_bytes;
-  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.no_chain, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
+  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.no_chain, &ix->plan.no_segments, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
   return SBWT_OK;
 }
 
@@ -1099,6 +1101,7 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
   w.sort_lds_bytes = ix->plan.sort_lds_bytes;
   w.no_bfs = ix->plan.no_bfs;
   w.no_chain = ix->plan.no_chain;
+  w.no_segments = ix->plan.no_segments;
   w.ring_width_max = ix->plan.ring_width_max;
   w.ring_chr_max = ix->plan.ring_chr_max;
   if (!w.grid_sort || !w.sm_ring_bytes) {

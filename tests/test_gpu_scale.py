@@ -135,6 +135,25 @@ def test_small_rna_multi_hit_reads(world):
         check(sb, ix, oix, reads[-400:], limit=limit, strand=strand)
 
 
+@pytest.mark.parametrize("knob", ["1", "2"])
+def test_small_multi_hit_reads_several_per_wave_or_one_at_a_time(world, monkeypatch, knob):
+    """k_multi_sort's wave teams locate reads of at most 8 / 64 rows several at a time (segments of the team's 256
+    entries); SBWT_NO_SEGMENTS, read when the ctx is made, switches that off (1) or leaves only the 64-entry segments (2):
+    the same records and lists, and the oracle's"""
+    sb, ix, oix, codes, fam, rng = world
+    reads = sample_reads(rng, codes, 3000, list(range(18, 31)))
+    for f, c in zip(fam, [2, 3, 5, 8, 13, 50, 200, 999, 1000, 1001, 1500] + [4] * 29):
+        for a, b in ((0, 30), (2, 24), (7, 30)):
+            s = f[a:b]
+            reads.append(bytes(b"ACGT"[c_] for c_ in s))
+            reads.append(bytes(b"ACGT"[c_] for c_ in (3 - s[::-1])))
+    res_a, nh, _ = check(sb, ix, oix, reads)
+    assert ((nh >= 2) & (nh <= 8)).sum() > 100 and ((nh > 8) & (nh <= 64)).sum() >= 6
+    monkeypatch.setenv("SBWT_NO_SEGMENTS", knob)
+    res_b, nh_b, _ = check(sb, ix, oix, reads)
+    np.testing.assert_array_equal(nh, nh_b)
+
+
 def test_hits_only_fast_pass_settles_most_reads(world):
     """SBWT_MAP_HITS_ONLY on an index with text in its hash slots: k_settle answers the reads its buckets settle with
     one access each and leaves the rest to the general kernels; hits, NH and flags equal the oracle's for every
