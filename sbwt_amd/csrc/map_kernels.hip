@@ -26,6 +26,7 @@
 #include "multi_locate.h"
 #include "settle.h"
 #include "direct.h"
+#include "rank_pass.h"
 
 namespace sbwt {
 
@@ -225,7 +226,9 @@ struct sbwt_ctx : MapWork {
   sbwt_hit* d_pend_hits = nullptr;
   uint64_t pend_words = 0, pend_lens_cap = 0, pend_out_cap = 0, pend_res_cap = 0, pend_hits_cap = 0;
   hipEvent_t ev_s[2] = {nullptr, nullptr};
-  uint32_t grid_settle = 0, grid_direct = 0;
+  uint32_t grid_settle = 0, grid_direct = 0, grid_rank = 0;
+  size_t rank_lds_bytes = 0;  // k_rank: the filter tables and sb_abs in LDS (0: from global memory)
+  bool no_rank = false;       // SBWT_NO_RANK_PASS
   float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
   bool no_settle = false, no_direct = false, no_spec = false;  // test knobs, read when the ctx is made
   uint64_t subbatch = 2u << 20;               // reads per sub-batch of the host-buffer entry points (SBWT_SUBBATCH; 0 = never split)
@@ -274,6 +277,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   read_pass_knobs(&c->no_bfs, &c->no_chain, &c->no_segments, &c->ring_width_max, &c->ring_chr_max);
   c->no_settle = getenv("SBWT_NO_SETTLE") != nullptr;
   c->no_direct = getenv("SBWT_NO_DIRECT") != nullptr;
+  c->no_rank = getenv("SBWT_NO_RANK_PASS") != nullptr;
   c->no_spec = getenv("SBWT_NO_SPECULATIVE_PENDING") != nullptr;
   if (const char* sb = getenv("SBWT_SUBBATCH")) c->subbatch = strtoull(sb, nullptr, 10);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -281,7 +285,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) e = hipHostMalloc(&c->h_ctr, 2 * sizeof(Counters));
   if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&c->d_dfs_queue, max_reads * sizeof(uint32_t));
-  if (e == hipSuccess && ix->d.hash_text) e = hipMalloc(&c->d_pend_list, max_reads * sizeof(uint32_t));
+  if (e == hipSuccess && (ix->d.hash_text || ix->d.pos_lines)) e = hipMalloc(&c->d_pend_list, max_reads * sizeof(uint32_t));
   if (e == hipSuccess && !getenv("SBWT_NO_SHARED_LISTS")) {
     uint32_t slots = 1u << 12;
     while (slots < max_reads && slots < (1u << 23)) slots <<= 1;
@@ -300,6 +304,16 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     if (e == hipSuccess)
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<3, true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
     if (e == hipSuccess) c->grid_direct = (uint32_t)(prop.multiProcessorCount * (per_cu_d > 0 ? per_cu_d : 1));
+    // k_rank (rank_pass.h): the same tables and sb_abs
+    const size_t n_super = (size_t)(((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1);
+    c->rank_lds_bytes = c->sort_lds_bytes ? c->sort_lds_bytes + 16 * n_super * sizeof(uint64_t) : 0;
+    if (c->rank_lds_bytes > 48 * 1024) c->rank_lds_bytes = 0;
+    int per_cu_r = 0;
+    if (e == hipSuccess) {
+      e = c->rank_lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<true>, 256, c->rank_lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<false>, 256, 0);
+    }
+    if (e == hipSuccess) c->grid_rank = (uint32_t)(prop.multiProcessorCount * (per_cu_r > 0 ? per_cu_r : 1));
   }
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
   c->multi_lanes = 256u * 1024u;
@@ -679,7 +693,10 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const bool plain = io.compact == nullptr;
   const bool settle = fast && !plain && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
   const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !c->no_direct;
-  if (!settle && !direct) {
+  // an index without the text-carrying table: the lockstep rank pass (rank_pass.h) for compact records of 64 bases
+  const bool rank = !d.hash_text && !plain && words_per_read == 4 && c->d_pend_list && d.pos_lines && !c->no_rank &&
+                    !(d.kmer_tab && (d.kmer_order & 1u));
+  if (!settle && !direct && !rank) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
       c->last_stats[6] = c->last_stats[7] = c->last_stats[10] = c->last_stats[13] = 0;
@@ -707,8 +724,10 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
   SBWT_HIP(hipMemsetAsync(c->d_ctr + 1, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : c->grid_direct);
-  if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : rank ? c->grid_rank : c->grid_direct);
+  if (rank && c->rank_lds_bytes) k_rank<true><<<grid, 256, c->rank_lds_bytes, c->stream>>>(d, sa);
+  else if (rank) k_rank<false><<<grid, 256, 0, c->stream>>>(d, sa);
+  else if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   else if (settle) k_settle<false><<<grid, 256, 0, c->stream>>>(d, sa);
   else if (plain && c->sort_lds_bytes) {
     if (words_per_read == 4) k_direct<1, true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
