@@ -555,7 +555,8 @@ class Run:
         out_bytes = 16 if self.compact else 48     # per read: one 16-byte record, or a 32-byte record + the 16-byte hit slot
         if A["settle_ms"] > 0:
             # the dominant kernel is the fast pass -- one bucket (one line) per looked-up read, records in, records out
-            A["kernel"], A["kernel_ms"] = ("k_settle" if (self.layout == "hits" and wpr == 4) else "k_direct"), A["settle_ms"]
+            fast = "k_rank" if getattr(self.wl, "rank_path", False) else "k_settle" if (self.layout == "hits" and wpr == 4) else "k_direct"
+            A["kernel"], A["kernel_ms"] = fast, A["settle_ms"]
             A["accesses"] = int(stats[6])
             A["streamed"] = n_reads * (wpr * 4 + 4 + out_bytes) + int(stats[7]) * 4
         else:

@@ -694,8 +694,7 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const bool settle = fast && !plain && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
   const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !c->no_direct;
   // an index without the text-carrying table: the lockstep rank pass (rank_pass.h) for compact records of 64 bases
-  const bool rank = !d.hash_text && !plain && words_per_read == 4 && c->d_pend_list && d.pos_lines && !c->no_rank &&
-                    !(d.kmer_tab && (d.kmer_order & 1u));
+  const bool rank = !d.hash_text && !plain && words_per_read == 4 && c->d_pend_list && d.pos_lines && !c->no_rank;
   if (!settle && !direct && !rank) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;

@@ -17,8 +17,8 @@
 //   text     the rest of the read against the window of the PosLine it ends on, and the final row from the same line
 //            (direct.h: eight lanes a line, pieces swizzled against the banks) -- one line
 //
-// and writes the 16-byte record.  Whatever leaves that pattern -- an interval that dies, several rows left at the end, a
-// prefix of odd order, a row the text does not answer for, a window that does not reach, a result no record holds -- is
+// and writes the 16-byte record.  Whatever leaves that pattern -- an interval that dies, several rows left at the end,
+// a row the text does not answer for, a window that does not reach, a result no record holds -- is
 // left PENDING for the general kernels exactly as k_settle / k_direct leave theirs.  The arithmetic is that of the
 // states it replaces.
 #pragma once
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
     // ---- prefix: one load (a read shorter than the memoised prefix takes the 12-mer pair)
     const bool use_tab = ix.kmer_tab != nullptr && L >= K;
     const uint32_t j0 = use_tab ? K : (uint32_t)kKmer;
-    bool go = pending && !(j0 & 1u);  // (two-base steps start at even j: a prefix of odd order is the general kernels' business)
+    bool go = pending;
     uint64_t lo = 0, hi = 0, p = 0;
     uint32_t j = j0;
     bool cmp = false;  // p holds the position the one row left reports; bases [j, L) remain
@@ -127,6 +127,22 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
         hi = u64_of(pair.z, pair.w);
       }
       if (go && !cmp && lo >= hi) go = false;  // (an empty interval: its record is the general kernels')
+    }
+    // ---- a prefix of odd order: two-base steps start at even j (the pair never straddles the halves of the record), so
+    // one base goes alone first (search_machine.h, S_LF1) -- for the few entries of such a table that are not a located row
+    {
+      const bool odd = go && !cmp && (j & 1u) && hi - lo > 1 && j < L;
+      if (__any(odd)) {
+        if (odd) {
+          const uint32_t c = ((uint32_t)(((j & 32u) ? w_hi : w_lo) >> (2 * (j & 31u))) & 3u) ^ 3u;
+          const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
+          lines_n += (lo >> 6) == (hi >> 6) ? 1u : 2u;
+          lo = l1;
+          hi = h1;
+          j += 1;
+          if (lo >= hi) go = false;  // (the interval died: its record is the general kernels')
+        }
+      }
     }
     // ---- steps: while the interval holds several rows and two bases are left
     bool second = false;   // this lane's next line is that of hi (lo's block is done: t_lo)

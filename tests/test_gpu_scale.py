@@ -154,6 +154,47 @@ def test_small_multi_hit_reads_several_per_wave_or_one_at_a_time(world, monkeypa
     np.testing.assert_array_equal(nh, nh_b)
 
 
+@pytest.mark.parametrize("env,runs", [({"SBWT_HASH_ORDER": "0", "SBWT_KMER_ORDER": "12"}, True),
+                                      ({"SBWT_HASH_ORDER": "0", "SBWT_KMER_ORDER": "14"}, True),
+                                      ({"SBWT_HASH_ORDER": "0", "SBWT_KMER_ORDER": "15"}, True),
+                                      ({"SBWT_HASH_ORDER": "16", "SBWT_HASH_TEXT": "0", "SBWT_KMER_ORDER": "12"}, True)])
+def test_lockstep_rank_pass_on_an_index_without_slot_text(world, monkeypatch, env, runs):
+    """k_rank (rank_pass.h): an index without the text-carrying hash table maps compact batches of 64-base records through
+    prefix entry -> two-base steps -> sa_full -> text comparison in lockstep and leaves the rest pending: every field of
+    every record (dead reads, multi-hit reads, short reads included) equals the oracle's, with the pass and without it
+    (SBWT_NO_RANK_PASS); memoised prefixes of even and odd order"""
+    sb, ix0, oix, codes, fam, rng = world
+    ix, _ = build_index(sb, codes, env)
+    try:
+        assert ix.info().hash_text == 0
+        reads = sample_reads(rng, codes, 12000, [12, 13, 20, 31, 36, 50, 51, 64])
+        for f in fam[:12]:
+            reads.append(bytes(b"ACGT"[c] for c in f))
+        packed, lens = sb.pack_reads(reads)
+        lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+        k = np.maximum(nh, 0)
+        oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SBWT_NO_RANK_PASS", "1")
+            ctx = sb.Context(ix, len(reads))
+            for mode in (0, sb.MAP_HITS_ONLY):
+                rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=mode)
+                t, st = ctx.last_timing_ex(), ctx.last_stats_ex()
+                assert (t[3] > 0) == (runs and not off)          # the fast pass ran / did not
+                if runs and not off:
+                    assert 0 < st[7] < 0.5 * len(reads)           # ... and settled most reads itself
+                res, hits = sb.compact_expand(rec, lists, wide)
+                np.testing.assert_array_equal(res["nh"], nh)
+                np.testing.assert_array_equal(res["sa_lo"], lo)
+                np.testing.assert_array_equal(res["sa_hi"], hi)
+                gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+                assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+            ctx.close()
+    finally:
+        ix.close()
+
+
 def test_hits_only_fast_pass_settles_most_reads(world):
     """SBWT_MAP_HITS_ONLY on an index with text in its hash slots: k_settle answers the reads its buckets settle with
     one access each and leaves the rest to the general kernels; hits, NH and flags equal the oracle's for every
