@@ -310,8 +310,8 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     if (c->rank_lds_bytes > 48 * 1024) c->rank_lds_bytes = 0;
     int per_cu_r = 0;
     if (e == hipSuccess) {
-      e = c->rank_lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<true>, 256, c->rank_lds_bytes)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<false>, 256, 0);
+      e = c->rank_lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<2, true>, 256, c->rank_lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<2, false>, 256, 0);
     }
     if (e == hipSuccess) c->grid_rank = (uint32_t)(prop.multiProcessorCount * (per_cu_r > 0 ? per_cu_r : 1));
   }
@@ -693,8 +693,8 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   const bool plain = io.compact == nullptr;
   const bool settle = fast && !plain && (mode & SBWT_MAP_HITS_ONLY) && words_per_read == 4;
   const bool direct = fast && !settle && words_per_read <= 12 && d.pos_lines && d.hash_order <= 31 && !c->no_direct;
-  // an index without the text-carrying table: the lockstep rank pass (rank_pass.h) for compact records of 64 bases
-  const bool rank = !d.hash_text && !plain && words_per_read == 4 && c->d_pend_list && d.pos_lines && !c->no_rank;
+  // an index without the text-carrying table: the lockstep rank pass (rank_pass.h) for records of 64 or 128 bases
+  const bool rank = !d.hash_text && (words_per_read == 4 || words_per_read == 8) && c->d_pend_list && d.pos_lines && !c->no_rank;
   if (!settle && !direct && !rank) {
     if (!accumulate) {
       c->last_ms_ex[0] = c->last_ms_ex[1] = 0.f;
@@ -724,9 +724,21 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   SBWT_HIP(hipMemsetAsync(c->d_ctr + 1, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : rank ? c->grid_rank : c->grid_direct);
-  if (rank && c->rank_lds_bytes) k_rank<true><<<grid, 256, c->rank_lds_bytes, c->stream>>>(d, sa);
-  else if (rank) k_rank<false><<<grid, 256, 0, c->stream>>>(d, sa);
-  else if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
+  if (rank) {
+    const bool lds = c->rank_lds_bytes != 0, two = words_per_read == 8;
+    const size_t lb = c->rank_lds_bytes;
+    if (plain) {
+      if (lds && two) k_rank<2, true, true><<<grid, 256, lb, c->stream>>>(d, sa);
+      else if (lds) k_rank<1, true, true><<<grid, 256, lb, c->stream>>>(d, sa);
+      else if (two) k_rank<2, false, true><<<grid, 256, 0, c->stream>>>(d, sa);
+      else k_rank<1, false, true><<<grid, 256, 0, c->stream>>>(d, sa);
+    } else {
+      if (lds && two) k_rank<2, true><<<grid, 256, lb, c->stream>>>(d, sa);
+      else if (lds) k_rank<1, true><<<grid, 256, lb, c->stream>>>(d, sa);
+      else if (two) k_rank<2, false><<<grid, 256, 0, c->stream>>>(d, sa);
+      else k_rank<1, false><<<grid, 256, 0, c->stream>>>(d, sa);
+    }
+  } else if (settle && c->sort_lds_bytes) k_settle<true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);
   else if (settle) k_settle<false><<<grid, 256, 0, c->stream>>>(d, sa);
   else if (plain && c->sort_lds_bytes) {
     if (words_per_read == 4) k_direct<1, true, true><<<grid, 256, c->sort_lds_bytes, c->stream>>>(d, sa);

@@ -33,9 +33,14 @@
 
 namespace sbwt {
 
-// a.packed: records of 4 words (64 bases); a.out: compact records (SA interval + hit)
-template <bool kLds>  // the filter tables and sb_abs are staged in LDS (the launch carries (n_chr + 2 n_npos + 16 n_super) * 8 bytes)
+// a.packed: records of 4 * kPiecesT words (64 or 128 bases); a.out: compact records (SA interval + hit), or -- kPlain --
+// a.results / a.hits: the 32-byte records of sbwt_map_batch_device with the hit of a read at hits[its own index]
+// kLds: the filter tables and sb_abs are staged in LDS (the launch carries (n_chr + 2 n_npos + 16 n_super) * 8 bytes)
+template <int kPiecesT, bool kLds, bool kPlain = false>
 __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const SettleArgs a) {
+  constexpr uint32_t kPieces = (uint32_t)kPiecesT;
+  constexpr bool kLong = kPiecesT >= 2;
+  constexpr uint32_t kMaxLen = 64u * kPieces;
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   __shared__ __attribute__((aligned(16))) uint4 s_img_all[4][512];  // per wave: the Block2 stage of a round, then the PosLines (8 KB)
   __shared__ uint32_t s_pend_all[4][kDirectBuf];
@@ -77,21 +82,35 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
   const uint64_t n_round = (a.n_reads + 63) & ~63ull;  // whole waves stay in the loop together (ballots, DPP, LDS-DMA)
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool valid = r < a.n_reads;
-  uint4 rec = make_uint4(0, 0, 0, 0);
+  uint4 rec = make_uint4(0, 0, 0, 0), rec2 = rec;
   uint32_t L = 0;
-  if (valid) { rec = recs[r]; L = a.lens[r]; }
+  if (valid) {
+    rec = recs[r * kPieces];
+    if (kLong) rec2 = recs[r * kPieces + 1];
+    L = a.lens[r];
+  }
   for (; r < n_round; r += stride) {
     // the record of the read after this one is on its way while this one's lines are awaited
     const uint64_t rn = r + stride;
     const bool nvalid = rn < a.n_reads;
-    uint4 nrec = make_uint4(0, 0, 0, 0);
+    uint4 nrec = make_uint4(0, 0, 0, 0), nrec2 = nrec;
     uint32_t nL = 0;
-    if (nvalid) { nrec = recs[rn]; nL = a.lens[rn]; }
+    if (nvalid) {
+      nrec = recs[rn * kPieces];
+      if (kLong) nrec2 = recs[rn * kPieces + 1];
+      nL = a.lens[rn];
+    }
 
     const uint64_t w_lo = u64_of(rec.x, rec.y), w_hi = u64_of(rec.z, rec.w);
+    const uint64_t w2 = u64_of(rec2.x, rec2.y), w3 = u64_of(rec2.z, rec2.w);  // bases 64..127 (kLong)
+    // the 32-base word base j lies in
+    auto word_of = [&](uint32_t jj) -> uint64_t {
+      if (kLong && (jj & 64u)) return (jj & 32u) ? w3 : w2;
+      return (jj & 32u) ? w_hi : w_lo;
+    };
     bool pending = valid;
     uint64_t e0 = 0, e1 = 0;  // the record
-    if (valid && (L < (uint32_t)kKmer || L > 64u)) {
+    if (valid && (L < (uint32_t)kKmer || L > kMaxLen)) {
       e1 = (uint64_t)R_INVALID << 56;  // as k_search_sm reports a read its record cannot hold: nothing mapped
       pending = false;
     }
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
       const bool odd = go && !cmp && (j & 1u) && hi - lo > 1 && j < L;
       if (__any(odd)) {
         if (odd) {
-          const uint32_t c = ((uint32_t)(((j & 32u) ? w_hi : w_lo) >> (2 * (j & 31u))) & 3u) ^ 3u;
+          const uint32_t c = ((uint32_t)(word_of(j) >> (2 * (j & 31u))) & 3u) ^ 3u;
           const uint64_t l1 = lf1(ix, lo, c), h1 = lf1(ix, hi, c);
           lines_n += (lo >> 6) == (hi >> 6) ? 1u : 2u;
           lo = l1;
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
     for (;;) {
       const bool stepping = go && !cmp && hi - lo > 1 && j + 2u <= L;
       if (!__any(stepping)) break;
-      const uint64_t wsel = (j & 32u) ? w_hi : w_lo;
+      const uint64_t wsel = word_of(j);
       const uint32_t two = ((uint32_t)(wsel >> (2 * (j & 31u))) & 15u) ^ 15u;  // complement: the query is RC(read)
       const uint32_t code = ((two & 3u) << 2) | (two >> 2);                    // x = first prepended base, y = second
       const uint64_t x = second ? hi : lo;
@@ -256,15 +275,32 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
       // the rem bases of the read from j on against the 128-base window from offset o on (search_machine.h, S_CMP)
       const uint32_t o = 128u - slot19 - rem;
       const uint64_t q0 = u64_of(ta.x, ta.y), q1 = u64_of(ta.z, ta.w), q2 = u64_of(tb.x, tb.y), q3 = u64_of(tb.z, tb.w);
-      uint64_t t0, t1, r0, r1;
-      if (o < 64u) sm_funnel128(q0, q1, q2, q3, o, t0, t1);
-      else sm_funnel128(q2, q3, 0, 0, o - 64u, t0, t1);
-      sm_funnel128(w_lo, w_hi, 0, 0, j, r0, r1);  // rem <= 52: two words hold them
-      uint64_t d_lo = r0 ^ t0, d_hi = r1 ^ t1;
-      if (rem < 32u) d_lo &= (1ull << (2 * rem)) - 1ull;
-      if (rem <= 32u) d_hi = 0;
-      else if (rem < 64u) d_hi &= (1ull << (2 * (rem - 32u))) - 1ull;
-      if ((d_lo | d_hi) == 0) {
+      uint64_t t0, t1, t2 = 0, t3 = 0, r0, r1, r2 = 0, r3 = 0;
+      if (o < 64u) {
+        sm_funnel128(q0, q1, q2, q3, o, t0, t1);
+        if (kLong) sm_funnel128(q2, q3, 0, 0, o, t2, t3);
+      } else {
+        sm_funnel128(q2, q3, 0, 0, o - 64u, t0, t1);
+      }
+      // bases [j, j + 128) of the record (j < 64 when kLong is off; a long read that stepped past base 63 keeps no window)
+      const uint32_t jo = j & 63u;
+      if (kLong && (j & 64u)) {
+        sm_funnel128(w2, w3, 0, 0, jo, r0, r1);
+      } else {
+        sm_funnel128(w_lo, w_hi, w2, w3, jo, r0, r1);
+        if (kLong) sm_funnel128(w2, w3, 0, 0, jo, r2, r3);
+      }
+      const uint64_t d[4] = {r0 ^ t0, r1 ^ t1, r2 ^ t2, r3 ^ t3};
+      bool differs = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t first = 32u * (uint32_t)q;  // this word covers bases [first, first + 32) of the rem
+        uint64_t dq = d[q];
+        if (rem <= first) dq = 0;
+        else if (rem < first + 32u) dq &= (1ull << (2 * (rem - first))) - 1ull;
+        differs = differs || dq != 0;
+      }
+      if (!differs) {
         // the interval is the one row the chain ends on; its position is pfin
         uint32_t meta = 0;
         uint64_t payload = 0;
@@ -291,7 +327,28 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
     }
     if (pending) ++other_n;
     // records leave as whole lines: a pending read's slot is written too (zeros) and overwritten by k_scatter_pending
-    if (valid) reinterpret_cast<uint4*>(a.out)[r] = make_uint4((uint32_t)e0, (uint32_t)(e0 >> 32), (uint32_t)e1, (uint32_t)(e1 >> 32));
+    if (kPlain) {
+      // 32-byte records (sm_emit's): a settled read is an interval of one row, or a read no record can hold
+      if (valid && !pending) {
+        const uint32_t meta = (uint32_t)(e1 >> 56);
+        sbwt_read_result res;
+        res.sa_lo = e0 & kPosMask;
+        res.sa_hi = res.sa_lo + (e0 >> kPosBits);
+        res.first_hit = (meta & R_NH) ? r : 0;
+        res.nh = (meta & R_NH) ? 1 : 0;
+        res.flags = ((meta >> R_FLAGS_SHIFT) & 3u) | ((meta & R_INVALID) ? kFlagInvalid : 0u);
+        a.results[r] = res;
+        if (meta & R_NH) {
+          sbwt_hit h;
+          h.pos0 = e1 & kPosMask;
+          h.chr_id = (uint32_t)(e1 >> kPosBits) & 0xFFFFu;
+          h.is_rc = (meta & R_RC) ? 1u : 0u;
+          a.hits[r] = h;
+        }
+      }
+    } else if (valid) {
+      reinterpret_cast<uint4*>(a.out)[r] = make_uint4((uint32_t)e0, (uint32_t)(e0 >> 32), (uint32_t)e1, (uint32_t)(e1 >> 32));
+    }
     const uint64_t pm = __ballot(pending);
     if (pm) {
       if (pending) s_pend[n_buf + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = (uint32_t)r;
@@ -300,6 +357,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
     }
     valid = nvalid;
     rec = nrec;
+    rec2 = nrec2;
     L = nL;
   }
   if (n_buf) flush_pending();

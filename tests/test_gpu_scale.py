@@ -167,30 +167,41 @@ def test_lockstep_rank_pass_on_an_index_without_slot_text(world, monkeypatch, en
     ix, _ = build_index(sb, codes, env)
     try:
         assert ix.info().hash_text == 0
-        reads = sample_reads(rng, codes, 12000, [12, 13, 20, 31, 36, 50, 51, 64])
-        for f in fam[:12]:
-            reads.append(bytes(b"ACGT"[c] for c in f))
-        packed, lens = sb.pack_reads(reads)
-        lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
-        k = np.maximum(nh, 0)
-        oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
-        for off in (False, True):
-            if off:
-                monkeypatch.setenv("SBWT_NO_RANK_PASS", "1")
-            ctx = sb.Context(ix, len(reads))
-            for mode in (0, sb.MAP_HITS_ONLY):
-                rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=mode)
-                t, st = ctx.last_timing_ex(), ctx.last_stats_ex()
-                assert (t[3] > 0) == (runs and not off)          # the fast pass ran / did not
-                if runs and not off:
-                    assert 0 < st[7] < 0.5 * len(reads)           # ... and settled most reads itself
-                res, hits = sb.compact_expand(rec, lists, wide)
+        for lens_ in ([12, 13, 20, 31, 36, 50, 51, 64], [30, 65, 80, 100, 127, 128]):   # records of 64 and of 128 bases
+            reads = sample_reads(rng, codes, 12000, lens_)
+            for f in fam[:12]:
+                reads.append(bytes(b"ACGT"[c] for c in f))
+            packed, lens = sb.pack_reads(reads)
+            lo, hi, nh, first, ohits = oix.map_batch(reads, nthreads=8)
+            k = np.maximum(nh, 0)
+            oi = np.repeat(first, k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+            for off in (False, True):
+                if off:
+                    monkeypatch.setenv("SBWT_NO_RANK_PASS", "1")
+                else:
+                    monkeypatch.delenv("SBWT_NO_RANK_PASS", raising=False)
+                ctx = sb.Context(ix, len(reads))
+                # the 32-byte records of sbwt_map_batch take the same pass
+                res, hits = ctx.map_batch(packed, lens)
+                assert (ctx.last_timing_ex()[3] > 0) == (runs and not off)
                 np.testing.assert_array_equal(res["nh"], nh)
                 np.testing.assert_array_equal(res["sa_lo"], lo)
                 np.testing.assert_array_equal(res["sa_hi"], hi)
                 gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
                 assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
-            ctx.close()
+                for mode in (0, sb.MAP_HITS_ONLY):
+                    rec, lists, wide = ctx.map_batch_compact(packed, lens, mode=mode)
+                    t, st = ctx.last_timing_ex(), ctx.last_stats_ex()
+                    assert (t[3] > 0) == (runs and not off)          # the fast pass ran / did not
+                    if runs and not off:
+                        assert 0 < st[7] < 0.5 * len(reads)           # ... and settled most reads itself
+                    res, hits = sb.compact_expand(rec, lists, wide)
+                    np.testing.assert_array_equal(res["nh"], nh)
+                    np.testing.assert_array_equal(res["sa_lo"], lo)
+                    np.testing.assert_array_equal(res["sa_hi"], hi)
+                    gi = np.repeat(res["first_hit"], k) + (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k))
+                    assert np.array_equal(hits[gi.astype(np.int64)], ohits[oi.astype(np.int64)])
+                ctx.close()
     finally:
         ix.close()
 
