@@ -77,7 +77,8 @@ struct sbwt_launch_plan {
   uint32_t grid_sm_lds = 0, grid_sm_glb = 0, grid_sort = 0, grid_bfs = 0;
   size_t sm_lds_bytes = 0, sm_ring_bytes = 0, sort_lds_bytes = 0;
   // test knobs of the entry point without a ctx, read when the index is made (map_kernels.hip: read_pass_knobs)
-  bool no_bfs = false, no_chain = false;
+  bool no_bfs = false, no_chain = false, no_rounds = false;
+  uint32_t grid_rounds_lds = 0, grid_rounds_glb = 0;
   uint32_t no_segments = 0;
   uint32_t ring_width_max = 0xFFFFFFu, ring_chr_max = 0xFFFFu;
 };

@@ -27,6 +27,7 @@
 #include "settle.h"
 #include "direct.h"
 #include "rank_pass.h"
+#include "search_rounds.h"
 
 namespace sbwt {
 
@@ -191,12 +192,14 @@ struct MapWork {
   uint32_t group_slots = 0;                   // a power of two; 0: no grouping (the no-allocation entry point)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // null: the pass is not timed ([3], [4]: around locate kernels launched in a second phase)
   // test knobs (environment variables, read ONCE: when the ctx is made, or -- the entry point without a ctx -- the index)
-  bool no_bfs = false, no_chain = false;
+  bool no_bfs = false, no_chain = false, no_rounds = false;
+  uint32_t grid_rounds_lds = 0, grid_rounds_glb = 0;  // k_search_rounds (search_rounds.h)
   uint32_t no_segments = 0;  // SBWT_NO_SEGMENTS: 1 = wave teams locate one read at a time, 2 = no segments of 8 entries
   uint32_t ring_width_max = (uint32_t)kRingWidthMax, ring_chr_max = 0xFFFFu;
 };
 
-static void read_pass_knobs(bool* no_bfs, bool* no_chain, uint32_t* no_segments, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
+static void read_pass_knobs(bool* no_bfs, bool* no_chain, bool* no_rounds, uint32_t* no_segments, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
+  *no_rounds = getenv("SBWT_NO_ROUNDS") != nullptr;
   const char* seg = getenv("SBWT_NO_SEGMENTS");
   *no_segments = seg && *seg ? (uint32_t)strtoul(seg, nullptr, 10) : 0u;
   *no_bfs = getenv("SBWT_NO_BFS") != nullptr;
@@ -259,6 +262,12 @@ static hipError_t plan_launches(const sbwt_index* ix, MapWork* w) {
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bfs_per_cu, k_multi_bfs<256, 512>, 256, w->sort_lds_bytes);
   if (e != hipSuccess) return e;
   w->grid_bfs = (uint32_t)(prop.multiProcessorCount * (bfs_per_cu > 0 ? bfs_per_cu : 1));
+  int rd_lds = 0, rd_glb = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&rd_lds, k_search_rounds<2, true>, 256, w->sm_lds_bytes);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&rd_glb, k_search_rounds<2, false>, 256, 0);
+  if (e != hipSuccess) return e;
+  w->grid_rounds_lds = (uint32_t)(prop.multiProcessorCount * (rd_lds > 0 ? rd_lds : 1));
+  w->grid_rounds_glb = (uint32_t)(prop.multiProcessorCount * (rd_glb > 0 ? rd_glb : 1));
   w->grid_sm_lds = (uint32_t)(prop.multiProcessorCount * (sm_lds > 0 ? sm_lds : 1));
   w->grid_sm_glb = (uint32_t)(prop.multiProcessorCount * (sm_glb > 0 ? sm_glb : 1));
   return hipSuccess;
@@ -274,7 +283,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (!c) return SBWT_ERR_NOMEM;
   c->ix = ix;
   c->max_reads = max_reads;
-  read_pass_knobs(&c->no_bfs, &c->no_chain, &c->no_segments, &c->ring_width_max, &c->ring_chr_max);
+  read_pass_knobs(&c->no_bfs, &c->no_chain, &c->no_rounds, &c->no_segments, &c->ring_width_max, &c->ring_chr_max);
   c->no_settle = getenv("SBWT_NO_SETTLE") != nullptr;
   c->no_direct = getenv("SBWT_NO_DIRECT") != nullptr;
   c->no_rank = getenv("SBWT_NO_RANK_PASS") != nullptr;
@@ -505,10 +514,16 @@ static int pass_search(const sbwt_index* ix, const MapWork& w, const uint32_t* d
     sa.ring_chr_max = w.ring_chr_max;
     const bool lds = w.sm_lds_bytes != 0;
     const uint64_t need = (n_reads + 255) / 256;  // a wave with fewer than 64 reads has nothing to overlap
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, lds ? w.grid_sm_lds : w.grid_sm_glb);
+    // records of up to 128 bases: the search in lockstep rounds (search_rounds.h); the state machine for longer ones
+    const bool rounds = words_per_read <= 8 && d.pos_lines && !w.no_rounds;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(need, rounds ? (lds ? w.grid_rounds_lds : w.grid_rounds_glb) : lds ? w.grid_sm_lds : w.grid_sm_glb);
     // records of more than 64 bases: the variant that holds two 64-base pieces and compares up to 128 bases at once
     const bool long_reads = words_per_read > 4;
-    if (lds && long_reads) k_search_sm<true, true><<<grid, 256, w.sm_lds_bytes + w.sm_ring_bytes, w.stream>>>(d, sa);
+    if (rounds && lds && long_reads) k_search_rounds<2, true><<<grid, 256, w.sm_lds_bytes, w.stream>>>(d, sa);
+    else if (rounds && lds) k_search_rounds<1, true><<<grid, 256, w.sm_lds_bytes, w.stream>>>(d, sa);
+    else if (rounds && long_reads) k_search_rounds<2, false><<<grid, 256, 0, w.stream>>>(d, sa);
+    else if (rounds) k_search_rounds<1, false><<<grid, 256, 0, w.stream>>>(d, sa);
+    else if (lds && long_reads) k_search_sm<true, true><<<grid, 256, w.sm_lds_bytes + w.sm_ring_bytes, w.stream>>>(d, sa);
     else if (lds) k_search_sm<true, false><<<grid, 256, w.sm_lds_bytes + w.sm_ring_bytes, w.stream>>>(d, sa);
     else if (long_reads) k_search_sm<false, true><<<grid, 256, w.sm_ring_bytes, w.stream>>>(d, sa);
     else k_search_sm<false, false><<<grid, 256, w.sm_ring_bytes, w.stream>>>(d, sa);
@@ -1065,12 +1080,14 @@ int sbwt::finish_index(sbwt_index* ix) {
   SBWT_HIP(plan_launches(ix, &w));
   ix->plan.grid_sm_lds = w.grid_sm_lds;
   ix->plan.grid_sm_glb = w.grid_sm_glb;
+  ix->plan.grid_rounds_lds = w.grid_rounds_lds;
+  ix->plan.grid_rounds_glb = w.grid_rounds_glb;
   ix->plan.grid_sort = w.grid_sort;
   ix->plan.grid_bfs = w.grid_bfs;
   ix->plan.sm_lds_bytes = w.sm_lds_bytes;
   ix->plan.sm_ring_bytes = w.sm_ring_bytes;
   ix->plan.sort_lds_bytes = w.sort_lds_bytes;
-  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.no_chain, &ix->plan.no_segments, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
+  read_pass_knobs(&ix->plan.no_bfs, &ix->plan.no_chain, &ix->plan.no_rounds, &ix->plan.no_segments, &ix->plan.ring_width_max, &ix->plan.ring_chr_max);
   return SBWT_OK;
 }
 
@@ -1131,6 +1148,9 @@ extern "C" int sbwt_map_batch_device_static(const sbwt_index* ix, void* stream, 
   w.sort_lds_bytes = ix->plan.sort_lds_bytes;
   w.no_bfs = ix->plan.no_bfs;
   w.no_chain = ix->plan.no_chain;
+  w.no_rounds = ix->plan.no_rounds;
+  w.grid_rounds_lds = ix->plan.grid_rounds_lds;
+  w.grid_rounds_glb = ix->plan.grid_rounds_glb;
   w.no_segments = ix->plan.no_segments;
   w.ring_width_max = ix->plan.ring_width_max;
   w.ring_chr_max = ix->plan.ring_chr_max;
