@@ -560,7 +560,7 @@ class Run:
             A["accesses"] = int(stats[6])
             A["streamed"] = n_reads * (wpr * 4 + 4 + out_bytes) + int(stats[7]) * 4
         else:
-            A["kernel"], A["kernel_ms"] = "k_search_sm", A["search_ms"]
+            A["kernel"], A["kernel_ms"] = ("k_search_rounds" if wpr <= 8 else "k_search_sm"), A["search_ms"]
             A["accesses"] = int(stats[0])
             A["streamed"] = n_reads * (wpr * 4 + 4 + out_bytes) + int(self.list_hits) * 16
         if A["multi_ms"] > A["kernel_ms"]:
