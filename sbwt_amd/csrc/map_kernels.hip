@@ -313,16 +313,6 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
     if (e == hipSuccess)
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, k_direct<3, true>, 256, ((size_t)ix->d.n_chr + 2 * (size_t)ix->d.n_npos) * sizeof(uint64_t));
     if (e == hipSuccess) c->grid_direct = (uint32_t)(prop.multiProcessorCount * (per_cu_d > 0 ? per_cu_d : 1));
-    // k_rank (rank_pass.h): the same tables and sb_abs
-    const size_t n_super = (size_t)(((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1);
-    c->rank_lds_bytes = c->sort_lds_bytes ? c->sort_lds_bytes + 16 * n_super * sizeof(uint64_t) : 0;
-    if (c->rank_lds_bytes > 48 * 1024) c->rank_lds_bytes = 0;
-    int per_cu_r = 0;
-    if (e == hipSuccess) {
-      e = c->rank_lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<2, true>, 256, c->rank_lds_bytes)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<2, false>, 256, 0);
-    }
-    if (e == hipSuccess) c->grid_rank = (uint32_t)(prop.multiProcessorCount * (per_cu_r > 0 ? per_cu_r : 1));
   }
   // k_multi runs a fixed number of lanes, each with its own DFS stack of `interval` frames
   c->multi_lanes = 256u * 1024u;
@@ -334,6 +324,20 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming);
   if (e == hipSuccess) e = plan_launches(ix, c);
+  if (e == hipSuccess) {
+    // k_rank (rank_pass.h): the filter tables (sort_lds_bytes, set by plan_launches) and sb_abs
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, ix->device);
+    const size_t n_super = (size_t)(((ix->d.n_blocks - 1) >> (kSuperShift - 6)) + 1);
+    c->rank_lds_bytes = c->sort_lds_bytes ? c->sort_lds_bytes + 16 * n_super * sizeof(uint64_t) : 0;
+    if (c->rank_lds_bytes > 48 * 1024) c->rank_lds_bytes = 0;
+    int per_cu_r = 0;
+    if (e == hipSuccess) {
+      e = c->rank_lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<2, true>, 256, c->rank_lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, k_rank<2, false>, 256, 0);
+    }
+    if (e == hipSuccess) c->grid_rank = (uint32_t)(prop.multiProcessorCount * (per_cu_r > 0 ? per_cu_r : 1));
+  }
   if (e == hipSuccess)
     e = hipMalloc(&c->d_wave_info, (size_t)std::max(c->grid_sm_lds, c->grid_sm_glb) * 4 * sizeof(WaveInfo));
   if (e != hipSuccess) {
