@@ -834,6 +834,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   constexpr uint32_t kSegMax = 32;
   __shared__ uint64_t s_seg_lo_all[4][kSegMax], s_seg_first_all[4][kSegMax];
   __shared__ uint32_t s_seg_m_all[4][kSegMax], s_seg_len_all[4][kSegMax], s_seg_bad_all[4][kSegMax];
+  __shared__ uint32_t s_seg_cnt[4][4];  // workgroup teams: accepted hits per (piece of 256 entries, wave)
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];  // (n_chr + 2 n_npos) words when a.lds_tables
   if (*a.overflow) return;  // the hit lists do not fit hits[]: the batch fails with SBWT_ERR_CAPACITY
   // push_position tables: LDS copies when they fit
@@ -875,15 +876,15 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
   uint32_t* const seg_bad = s_seg_bad_all[team];
   auto seg_pass = [&](auto seg_size, const uint32_t* lst, uint32_t nseg, const WaveInfo& wi) {
     constexpr uint32_t kS = decltype(seg_size)::value;
-    static_assert(256u / kS <= kSegMax, "segment descriptors");
-    if (lane < nseg) {
-      const uint32_t r = lst[lane];
+    static_assert(kCap / kS <= kSegMax && kCap % kS == 0, "segment descriptors");
+    if (tid < nseg) {
+      const uint32_t r = lst[tid];
       const MultiRead mr = rio_load(a.io, r);
-      seg_lo[lane] = mr.lo;
-      seg_m[lane] = (uint32_t)(mr.hi - mr.lo);
-      seg_first[lane] = mr.first_hit + a.multi_base + wi.slots;  // wave-relative until now
-      seg_len[lane] = a.lens[r];
-      seg_bad[lane] = 0;
+      seg_lo[tid] = mr.lo;
+      seg_m[tid] = (uint32_t)(mr.hi - mr.lo);
+      seg_first[tid] = mr.first_hit + a.multi_base + wi.slots;  // wave-relative until now
+      seg_len[tid] = a.lens[r];
+      seg_bad[tid] = 0;
     }
     team_sync<T>();
     uint64_t e4[4];
@@ -891,14 +892,14 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
     bool live[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t x = lane + 64u * (uint32_t)kk, g = x / kS, i = x % kS;
+      const uint32_t x = tid + (uint32_t)T * (uint32_t)kk, g = x / kS, i = x % kS;
       live[kk] = g < nseg && i < seg_m[g];
       len4[kk] = g < nseg ? seg_len[g] : 0u;
       e4[kk] = live[kk] ? ix.sa_full[seg_lo[g] + i] : kNoPosition;
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t g = (lane + 64u * (uint32_t)kk) / kS;
+      const uint32_t g = (tid + (uint32_t)T * (uint32_t)kk) / kS;
       const uint64_t p = e4[kk] & kPosMask;
       // a row the text does not answer for: its read goes to k_multi_chain / the walk
       if (live[kk] && (e4[kk] == kNoPosition || (e4[kk] >> kPosBits) < (p + 1 < ix.interval ? p + 1 : ix.interval))) seg_bad[g] = 1u;
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
     team_sync<T>();
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t g = (lane + 64u * (uint32_t)kk) / kS;
+      const uint32_t g = (tid + (uint32_t)T * (uint32_t)kk) / kS;
       live[kk] = live[kk] && !seg_bad[g];
     }
     // the text windows, pair-cooperative (as below)
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
     const bool pow2 = (ix.interval & (ix.interval - 1u)) == 0;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t x = lane + 64u * (uint32_t)kk, g = x / kS;
+      const uint32_t x = tid + (uint32_t)T * (uint32_t)kk, g = x / kS;
       // (an unused entry: above every key of a row; not all ones, because these entries ARE merged -- an element of a right
       // run is compared through y + 1, merge_by_rank)
       ulonglong2 key = make_ulonglong2(~0ull, ~0ull - 1ull);
@@ -971,23 +972,56 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
       sort_lds.ta[x] = (uint16_t)x;
     }
     team_sync<T>();
-    const SortedRows sorted = merge_by_rank<T>(sort_lds.ka, sort_lds.kb, sort_lds.ta, sort_lds.tb, 256u, kS, lane);
+    const SortedRows sorted = merge_by_rank<T>(sort_lds.ka, sort_lds.kb, sort_lds.ta, sort_lds.tb, kCap, kS, tid);
     // every segment's rows in emission order: compact those that passed the filters, write
+    uint64_t bal4[4];
+    uint64_t py4[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t k = lane + 64u * (uint32_t)kk, g = k / kS, i = k % kS;
+      const uint32_t k = tid + (uint32_t)T * (uint32_t)kk, g = k / kS;
       const bool seg = g < nseg, bad = seg && seg_bad[g] != 0;
-      uint64_t py = 0;
-      if (seg && !bad) py = pay[sorted.ord[k]];
+      py4[kk] = seg && !bad ? pay[sorted.ord[k]] : 0ull;
+      bal4[kk] = __ballot((py4[kk] & kPayOk) != 0);
+    }
+    if (T == 256) {
+      // a segment spans waves: the accepted hits of every (kk, wave) piece, through LDS
+      static_assert(T != 256 || kS % 256u == 0, "workgroup teams: a segment is whole pieces of 256 entries");
+      const uint32_t wave = threadIdx.x >> 6;
+      if (lane == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s_seg_cnt[kk][wave] = (uint32_t)__popcll(bal4[kk]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const uint32_t k = tid + (uint32_t)T * (uint32_t)kk, g = k / kS, i = k % kS;
+      const bool seg = g < nseg, bad = seg && seg_bad[g] != 0;
+      const uint64_t py = py4[kk];
       const bool ok = (py & kPayOk) != 0;
-      const uint64_t bal = __ballot(ok);
-      const uint64_t mine_bits = kS == 64 ? bal : (bal >> (lane & ~(kS - 1u))) & ((1ull << (kS & 63u)) - 1ull);
+      uint32_t before, total;  // accepted hits of this segment in front of this entry; in all of it
+      if (T == 64) {
+        const uint64_t mine_bits = kS == 64 ? bal4[kk] : (bal4[kk] >> (lane & ~(kS - 1u))) & ((1ull << (kS & 63u)) - 1ull);
+        before = (uint32_t)__popcll(mine_bits & ((1ull << (i & 63u)) - 1ull));
+        total = (uint32_t)__popcll(mine_bits);
+      } else {
+        constexpr uint32_t kPer = kS / 256u > 0 ? kS / 256u : 1u;  // pieces (kk) of a segment
+        const uint32_t wave = threadIdx.x >> 6, k0 = ((uint32_t)kk / kPer) * kPer;
+        before = (uint32_t)__popcll(bal4[kk] & ((1ull << lane) - 1ull));
+        total = 0;
+        for (uint32_t q = k0; q < k0 + kPer; ++q)
+          for (uint32_t v = 0; v < 4; ++v) {
+            const uint32_t c = s_seg_cnt[q][v];
+            total += c;
+            if (q < (uint32_t)kk || (q == (uint32_t)kk && v < wave)) before += c;
+          }
+      }
       if (ok) {
         sbwt_hit h;
         h.pos0 = py & kPosMask;
         h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
         h.is_rc = (uint32_t)(py >> 56) & 1u;
-        a.hits[seg_first[g] + (uint32_t)__popcll(mine_bits & ((1ull << i) - 1ull))] = h;
+        a.hits[seg_first[g] + before] = h;
       }
       if (seg && i == 0) {
         const uint32_t r = lst[g];
@@ -995,7 +1029,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
           rio_store_multi(a.io, r, seg_first[g], false, 0, 0u);
           a.dfs_queue[atomicAdd(a.dfs_count, 1ull)] = r;
         } else {
-          rio_store_multi(a.io, r, seg_first[g], true, (int32_t)__popcll(mine_bits), 0u);
+          rio_store_multi(a.io, r, seg_first[g], true, (int32_t)total, 0u);
           rows_done += seg_m[g];
         }
       }
@@ -1017,6 +1051,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
         mine = T == 64 ? m <= kCap : m > kSortMax / 4;
         if (mine && a.grp.keys) mine = group_leader(a.grp, my_r, mr.lo, m, a.lens[my_r]) == my_r;
         if (T == 64 && !no_sort_path && a.no_segments != 1u) cls = m <= 8 && a.no_segments != 2u ? 0u : m <= 64 ? 1u : 2u;
+        if (T == 256 && !no_sort_path && a.no_segments != 1u) cls = m <= 512 ? 0u : 2u;  // two reads of up to 512 rows at a time
       }
       uint32_t n_list, n_cls0 = 0, n_cls1 = 0;
       {
@@ -1031,12 +1066,18 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
           off = cls == 0 ? (uint32_t)__popcll(b0 & lt) : cls == 1 ? n_cls0 + (uint32_t)__popcll(b1 & lt) : n_cls0 + n_cls1 + (uint32_t)__popcll(b2 & lt);
         }
         if (T == 256) {
+          // the list in the order of the classes: those of class 0 of every wave, then the others
           const uint32_t wave = threadIdx.x >> 6;
-          __syncthreads();  // the previous batch is done with list and s_scan_all
-          if (lane == 0) s_scan_all[wave] = (uint32_t)__popcll(bal);
+          const uint64_t lt = (1ull << lane) - 1ull;
+          const uint64_t b0 = __ballot(mine && cls == 0), b2 = __ballot(mine && cls != 0);
+          __syncthreads();  // the previous batch is done with list and s_seg_cnt
+          if (lane == 0) { s_seg_cnt[0][wave] = (uint32_t)__popcll(b0); s_seg_cnt[1][wave] = (uint32_t)__popcll(b2); }
           __syncthreads();
-          for (uint32_t v = 0; v < wave; ++v) off += s_scan_all[v];
-          n_list = s_scan_all[0] + s_scan_all[1] + s_scan_all[2] + s_scan_all[3];
+          n_cls0 = s_seg_cnt[0][0] + s_seg_cnt[0][1] + s_seg_cnt[0][2] + s_seg_cnt[0][3];
+          n_list = n_cls0 + s_seg_cnt[1][0] + s_seg_cnt[1][1] + s_seg_cnt[1][2] + s_seg_cnt[1][3];
+          off = cls == 0 ? (uint32_t)__popcll(b0 & lt) : n_cls0 + (uint32_t)__popcll(b2 & lt);
+          for (uint32_t v = 0; v < wave; ++v) off += s_seg_cnt[cls == 0 ? 0 : 1][v];
+          __syncthreads();  // (s_seg_cnt is written again by seg_pass)
         } else {
           n_list = (uint32_t)__popcll(bal);
         }
@@ -1044,6 +1085,9 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
       }
       team_sync<T>();
       SBWT_PHASE(0);
+      if constexpr (T == 256) {
+        for (uint32_t at = 0; at < n_cls0; at += 2) seg_pass(std::integral_constant<uint32_t, 512>{}, list + at, n_cls0 - at < 2u ? n_cls0 - at : 2u, wi);
+      }
       if constexpr (T == 64) {
         for (uint32_t at = 0; at < n_cls0; at += 32) seg_pass(std::integral_constant<uint32_t, 8>{}, list + at, n_cls0 - at < 32u ? n_cls0 - at : 32u, wi);
         for (uint32_t at = 0; at < n_cls1; at += 4) seg_pass(std::integral_constant<uint32_t, 64>{}, list + n_cls0 + at, n_cls1 - at < 4u ? n_cls1 - at : 4u, wi);

@@ -206,6 +206,50 @@ def test_lockstep_rank_pass_on_an_index_without_slot_text(world, monkeypatch, en
         ix.close()
 
 
+def test_reads_of_257_to_512_rows_two_per_workgroup(oracle, monkeypatch):
+    """k_multi_sort's workgroup teams locate reads of 257..512 rows two at a time (segments of 512 entries): a genome with
+    repeat families of 256, 257, 300, 400, 512, 513 and 700 copies, reads inside them on both strands, against the oracle;
+    with SBWT_NO_SEGMENTS the same reads one at a time"""
+    import sbwt_amd as sb
+    sb.device_count()
+    rng = np.random.default_rng(512)
+    g = 3_000_000
+    codes = rng.integers(0, 4, g).astype(np.uint8)
+    copies = [256, 257, 300, 300, 400, 400, 512, 512, 513, 700]
+    slots = rng.permutation(g // 64 - 2)[:sum(copies)] * 64 + 5
+    fam = rng.integers(0, 4, (len(copies), 32)).astype(np.uint8)
+    k = 0
+    for f, c in zip(fam, copies):
+        for _ in range(c):
+            codes[slots[k]: slots[k] + 32] = f
+            k += 1
+    ix, tables = build_index(sb, codes, {"SBWT_HASH_ORDER": "20"}, want_tables=True)
+    T = tables.contents
+    c4 = (C.c_uint64 * 4)(*T.c_function4)
+    h = oracle.lib().sbo_index_wrap(T.interval, T.n, T.first_location, T.real_size, C.addressof(c4), T.c_functions, T.occ[0],
+                                    T.occ[1], T.occ[2], T.occ[3], T.occ_len, T.jbwt_seq, T.fbwt, T.location_table, T.n_loc,
+                                    CHR_START.size, CHR_START.ctypes.data, NPOS_KEY.size, NPOS_KEY.ctypes.data, NPOS_VAL.ctypes.data)
+    oix = oracle.OracleIndex(h, keep=(c4, CHR_START, NPOS_KEY, NPOS_VAL))
+    try:
+        reads = sample_reads(rng, codes, 500, [30, 40])
+        for f in fam:
+            for a, b in ((0, 32), (0, 24), (3, 30), (8, 32), (1, 25)):
+                s_ = f[a:b]
+                reads.append(bytes(b"ACGT"[c_] for c_ in s_))
+                reads.append(bytes(b"ACGT"[c_] for c_ in (3 - s_[::-1])))
+        res, nh, _ = check(sb, ix, oix, reads)
+        assert ((nh > 256) & (nh <= 512)).sum() >= 60 and (nh > 512).sum() >= 10
+        for lim in (300, 1000):
+            check(sb, ix, oix, reads[500:], limit=lim)
+        monkeypatch.setenv("SBWT_NO_SEGMENTS", "1")
+        res_b, nh_b, _ = check(sb, ix, oix, reads)
+        np.testing.assert_array_equal(nh, nh_b)
+    finally:
+        oix.close()
+        ix.close()
+        sb.host_tables_free(tables)
+
+
 def test_hits_only_fast_pass_settles_most_reads(world):
     """SBWT_MAP_HITS_ONLY on an index with text in its hash slots: k_settle answers the reads its buckets settle with
     one access each and leaves the rest to the general kernels; hits, NH and flags equal the oracle's for every
