@@ -284,21 +284,8 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
     rec3 = nrec3;
     L = nL;
   }
-  if (n_buf) flush_pending();
-  for (int d = 32; d > 0; d >>= 1) {
-    looked += __shfl_xor(looked, d);
-    found_n += __shfl_xor(found_n, d);
-    other_n += __shfl_xor(other_n, d);
-    lines_n += __shfl_xor(lines_n, d);
-    absent_n += __shfl_xor(absent_n, d);
-  }
-  if (lane == 0 && absent_n && a.absent_count) atomicAdd(a.absent_count, (unsigned long long)absent_n);
-  if (lane == 0 && looked) {
-    atomicAdd(a.index_accesses, (unsigned long long)lines_n);
-    atomicAdd(a.hash_stats, (unsigned long long)looked);
-    atomicAdd(a.hash_stats + 1, (unsigned long long)found_n);
-  }
-  if (lane == 0 && other_n) atomicAdd(a.pending_other, (unsigned long long)other_n);
+  const uint32_t tallies[5] = {looked, found_n, other_n, absent_n, lines_n};
+  settle_epilogue(a, s_pend, n_buf, tallies, lane);  // (settle.h: one set of atomics per workgroup)
 }
 
 }  // namespace sbwt

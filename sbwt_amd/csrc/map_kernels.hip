@@ -198,6 +198,8 @@ struct MapWork {
   uint32_t ring_width_max = (uint32_t)kRingWidthMax, ring_chr_max = 0xFFFFu;
 };
 
+constexpr uint32_t kFastGridMax = 16384;  // workgroups of a fast-pass launch (SettleArgs::wg_stats has room for as many)
+
 static void read_pass_knobs(bool* no_bfs, bool* no_chain, bool* no_rounds, uint32_t* no_segments, uint32_t* ring_width_max, uint32_t* ring_chr_max) {
   *no_rounds = getenv("SBWT_NO_ROUNDS") != nullptr;
   const char* seg = getenv("SBWT_NO_SEGMENTS");
@@ -230,6 +232,7 @@ struct sbwt_ctx : MapWork {
   uint64_t pend_words = 0, pend_lens_cap = 0, pend_out_cap = 0, pend_res_cap = 0, pend_hits_cap = 0;
   hipEvent_t ev_s[2] = {nullptr, nullptr};
   uint32_t grid_settle = 0, grid_direct = 0, grid_rank = 0;
+  unsigned long long* d_wg_stats = nullptr;  // SettleArgs::wg_stats: kFastGridMax x 5 tallies
   size_t rank_lds_bytes = 0;  // k_rank: the filter tables and sb_abs in LDS (0: from global memory)
   bool no_rank = false;       // SBWT_NO_RANK_PASS
   float last_ms_ex[2] = {0, 0};  // k_settle; the pass over the pending reads
@@ -295,6 +298,7 @@ extern "C" int sbwt_ctx_create(const sbwt_index* ix, uint64_t max_reads, sbwt_ct
   if (e == hipSuccess) e = hipMalloc(&c->d_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&c->d_dfs_queue, max_reads * sizeof(uint32_t));
   if (e == hipSuccess && (ix->d.hash_text || ix->d.pos_lines)) e = hipMalloc(&c->d_pend_list, max_reads * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&c->d_wg_stats, (size_t)kFastGridMax * 5 * sizeof(unsigned long long));
   if (e == hipSuccess && !getenv("SBWT_NO_SHARED_LISTS")) {
     uint32_t slots = 1u << 12;
     while (slots < max_reads && slots < (1u << 23)) slots <<= 1;
@@ -361,6 +365,7 @@ extern "C" void sbwt_ctx_free(sbwt_ctx* c) {
   hipFree(c->d_wave_info);
   hipFree(c->d_stacks);
   hipFree(c->d_packed); hipFree(c->d_lens); hipFree(c->d_results); hipFree(c->d_hits); hipFree(c->d_wide);
+  hipFree(c->d_wg_stats);
   hipFree(c->d_pend_list); hipFree(c->d_pend_packed); hipFree(c->d_pend_lens); hipFree(c->d_pend_out); hipFree(c->d_pend_res); hipFree(c->d_pend_hits);
   for (int k = 0; k < 2; ++k)
     if (c->ev_s[k]) hipEventDestroy(c->ev_s[k]);
@@ -740,9 +745,10 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
   sa.lds_tables = c->sort_lds_bytes ? 1u : 0u;
   sa.ring_chr_max = c->ring_chr_max;
   sa.hits_only = (mode & SBWT_MAP_HITS_ONLY) ? 1u : 0u;
+  sa.wg_stats = c->d_wg_stats;
   SBWT_HIP(hipMemsetAsync(c->d_ctr + 1, 0, sizeof(Counters), c->stream));
   SBWT_HIP(hipEventRecord(c->ev_s[0], c->stream));
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + 255) / 256, settle ? c->grid_settle : rank ? c->grid_rank : c->grid_direct);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((n_reads + 255) / 256, kFastGridMax), settle ? c->grid_settle : rank ? c->grid_rank : c->grid_direct);
   if (rank) {
     const bool lds = c->rank_lds_bytes != 0, two = words_per_read == 8;
     const size_t lb = c->rank_lds_bytes;
@@ -776,6 +782,8 @@ static int map_pass_compact(sbwt_ctx* c, const uint32_t* d_packed, const uint32_
     else if (words_per_read == 8) k_direct<2, false><<<grid, 256, 0, c->stream>>>(d, sa);
     else k_direct<3, false><<<grid, 256, 0, c->stream>>>(d, sa);
   }
+  SBWT_LAUNCHED();
+  k_fast_stats<<<1, 256, 0, c->stream>>>(c->d_wg_stats, grid, sa);  // the tallies of the launch's workgroups into the counters
   SBWT_LAUNCHED();
   SBWT_HIP(hipEventRecord(c->ev_s[1], c->stream));
   Counters* const hf = c->h_ctr + 1;  // the fast pass counts in the second Counters of the ctx: the general kernels zero the first

@@ -360,14 +360,9 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
     rec2 = nrec2;
     L = nL;
   }
-  if (n_buf) flush_pending();
-  for (int d = 32; d > 0; d >>= 1) {
-    lines_n += __shfl_xor(lines_n, d);
-    other_n += __shfl_xor(other_n, d);
-  }
-  if (lane == 0 && lines_n) atomicAdd(a.index_accesses, (unsigned long long)lines_n);
   // (every pending read still wants its hash lookup, where the index has an 8-byte-slot table: none was made here)
-  if (lane == 0 && other_n) atomicAdd(a.pending_other, (unsigned long long)other_n);
+  const uint32_t tallies[5] = {0u, 0u, other_n, 0u, lines_n};
+  settle_epilogue(a, s_pend, n_buf, tallies, lane);  // (settle.h: one set of atomics per workgroup)
 }
 
 }  // namespace sbwt

@@ -40,6 +40,7 @@ struct SettleArgs {
   uint32_t lds_tables;                  // the launch carries (n_chr + 2 n_npos) * 8 bytes of LDS for the filter tables
   uint32_t ring_chr_max;                // chr_id a record holds (test knob, as in SmArgs)
   uint32_t hits_only;                   // k_direct: SBWT_MAP_HITS_ONLY (a read that differs from the text is settled: no hit)
+  unsigned long long* wg_stats = nullptr;  // [gridDim.x][5]: the tallies of every workgroup, summed by k_fast_stats (null: atomics)
 };
 
 // The four lanes of a quad look their buckets up together.  Round k: the quad loads the bucket of its lane k, lane
@@ -109,7 +110,59 @@ __device__ __forceinline__ void settle_lookup(const DeviceIndex& ix, const uint4
   }
 }
 
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int d) {
+  return ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, d);
+}
+
 constexpr uint32_t kSettleBuf = 512;  // pending indices a wave holds in LDS before it reserves list slots for them
+
+// The end of a fast-pass kernel (k_settle, k_direct, k_rank; blocks of four waves, every thread gets here): what the
+// waves still hold of the pending list, and the tallies, leave with ONE set of atomics per workgroup.  All waves of a
+// launch finish within microseconds of each other, and atomics on one cache line run at about 1.2e8 per second: five per
+// wave -- 30,000 for the 6,144 waves of a launch -- were a quarter of a millisecond at the end of EVERY launch, whatever
+// its size (k_settle: 260 us for 10^6 reads, 570 us for 10^7).
+// tallies: {hash lookups, found, pending reads not looked up and missed, reads settled by a miss, index lines}
+__device__ __forceinline__ void settle_epilogue(const SettleArgs& a, const uint32_t* s_pend, uint32_t n_buf, const uint32_t (&tallies)[5],
+                                                uint32_t lane) {
+  __shared__ uint32_t s_left[4];
+  __shared__ unsigned long long s_sum[4][5];
+  __shared__ unsigned long long s_list_base;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t t[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    t[q] = tallies[q];
+    for (int d = 32; d > 0; d >>= 1) t[q] += __shfl_xor(t[q], d);
+  }
+  if (lane == 0) {
+    s_left[wave] = n_buf;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s_sum[wave][q] = t[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t left = s_left[0] + s_left[1] + s_left[2] + s_left[3];
+    s_list_base = left ? atomicAdd(a.pending_count, (unsigned long long)left) : 0ull;
+    unsigned long long sum[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) sum[q] = s_sum[0][q] + s_sum[1][q] + s_sum[2][q] + s_sum[3][q];
+    if (a.wg_stats) {
+      // no atomics at all for the tallies: k_fast_stats adds the workgroups up behind this kernel
+#pragma unroll
+      for (int q = 0; q < 5; ++q) a.wg_stats[(size_t)blockIdx.x * 5 + q] = sum[q];
+    } else {
+    if (sum[0] && a.hash_stats) atomicAdd(a.hash_stats, sum[0]);
+    if (sum[1] && a.hash_stats) atomicAdd(a.hash_stats + 1, sum[1]);
+    if (sum[2]) atomicAdd(a.pending_other, sum[2]);
+    if (sum[3] && a.absent_count) atomicAdd(a.absent_count, sum[3]);
+    if (sum[4]) atomicAdd(a.index_accesses, sum[4]);
+    }
+  }
+  __syncthreads();
+  unsigned long long base = s_list_base;
+  for (uint32_t v = 0; v < wave; ++v) base += s_left[v];
+  for (uint32_t k = lane; k < n_buf; k += 64) a.pending_list[base + k] = s_pend[k];
+}
 
 // kLds: the filter tables are staged in LDS (the launch carries (n_chr + 2 n_npos) * 8 bytes of it): a compile-time
 // choice, so that their reads are LDS instructions and not flat loads
@@ -254,21 +307,33 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     rec = nrec;
     L = nL;
   }
-  if (n_buf) flush_pending();
-  for (int d = 32; d > 0; d >>= 1) {
-    looked += __shfl_xor(looked, d);
-    found_n += __shfl_xor(found_n, d);
-    other_n += __shfl_xor(other_n, d);
-    absent_n += __shfl_xor(absent_n, d);
-    lines_n += __shfl_xor(lines_n, d);
+  const uint32_t tallies[5] = {looked, found_n, other_n, absent_n, lines_n};
+  settle_epilogue(a, s_pend, n_buf, tallies, lane);
+}
+
+// the tallies of a fast-pass launch (SettleArgs::wg_stats), added into the counters the host reads: one workgroup
+__global__ __launch_bounds__(256) void k_fast_stats(const unsigned long long* __restrict__ wg, uint32_t n_wg, SettleArgs a) {
+  __shared__ unsigned long long s_part[4][5];
+  unsigned long long t[5] = {0, 0, 0, 0, 0};
+  for (uint32_t i = threadIdx.x; i < n_wg; i += blockDim.x)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) t[q] += wg[(size_t)i * 5 + q];
+#pragma unroll
+  for (int q = 0; q < 5; ++q)
+    for (int d = 32; d > 0; d >>= 1) t[q] += shfl_xor_u64(t[q], d);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s_part[threadIdx.x >> 6][q] = t[q];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long sum[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) sum[q] = s_part[0][q] + s_part[1][q] + s_part[2][q] + s_part[3][q];
+    if (a.hash_stats) { a.hash_stats[0] += sum[0]; a.hash_stats[1] += sum[1]; }
+    *a.pending_other += sum[2];
+    if (a.absent_count) *a.absent_count += sum[3];
+    *a.index_accesses += sum[4];
   }
-  if (lane == 0 && absent_n && a.absent_count) atomicAdd(a.absent_count, (unsigned long long)absent_n);
-  if (lane == 0 && looked) {
-    atomicAdd(a.index_accesses, (unsigned long long)lines_n);
-    atomicAdd(a.hash_stats, (unsigned long long)looked);
-    atomicAdd(a.hash_stats + 1, (unsigned long long)found_n);
-  }
-  if (lane == 0 && other_n) atomicAdd(a.pending_other, (unsigned long long)other_n);
 }
 
 // the pending reads as a dense batch: record (`pieces` 16-byte pieces) and length of read list[i] at slot i
