@@ -105,20 +105,29 @@ struct MultiSortArgs {
 __global__ __launch_bounds__(1024) void k_multi_plan(WaveInfo* __restrict__ wi, uint32_t n_waves, uint64_t multi_base,
                                                      uint64_t hits_cap, unsigned long long* total_slots,
                                                      unsigned long long* total_count, unsigned int* overflow) {
-  __shared__ uint64_t s_slots[1024];
-  __shared__ uint32_t s_count[1024];
+  __shared__ uint64_t s_slots[16];
+  __shared__ uint32_t s_count[16];
   const uint32_t per = (n_waves + 1023u) / 1024u;
   const uint32_t a = threadIdx.x * per < n_waves ? threadIdx.x * per : n_waves;
   const uint32_t b = a + per < n_waves ? a + per : n_waves;
   uint64_t slots = 0;
   uint32_t count = 0;
   for (uint32_t w = a; w < b; ++w) { slots += wi[w].slots; count += wi[w].count; }
-  s_slots[threadIdx.x] = slots;
-  s_count[threadIdx.x] = count;
+  // exclusive prefix over the 1,024 threads: shuffles inside a wave, the sixteen wave totals through LDS
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t is = slots;
+  uint32_t ic = count;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t us = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(is >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)is, d);
+    const uint32_t uc = (uint32_t)__shfl_up((int)ic, d);
+    if ((int)lane >= d) { is += us; ic += uc; }
+  }
+  if (lane == 63) { s_slots[wave] = is; s_count[wave] = ic; }
   __syncthreads();
-  uint64_t ps = 0;
-  uint32_t pc = 0;
-  for (uint32_t t = 0; t < threadIdx.x; ++t) { ps += s_slots[t]; pc += s_count[t]; }
+  uint64_t ps = is - slots;
+  uint32_t pc = ic - count;
+  for (uint32_t v = 0; v < wave; ++v) { ps += s_slots[v]; pc += s_count[v]; }
   for (uint32_t w = a; w < b; ++w) {
     const uint64_t sl = wi[w].slots;
     const uint32_t cn = wi[w].count;

@@ -448,8 +448,15 @@ __global__ __launch_bounds__(256) void k_search_rounds(const DeviceIndex ix, con
     wi.queue_base = 0;
     a.wave_info[wave] = wi;
   }
+  // the tally: one atomic per workgroup (all waves of a launch end together, and atomics on one line serialise: settle.h)
+  __shared__ uint32_t s_tally[4];
   for (int d = 32; d > 0; d >>= 1) tally += __shfl_xor(tally, d);
-  if (lane == 0 && tally) atomicAdd(a.index_accesses, (unsigned long long)tally);
+  if (lane == 0) s_tally[threadIdx.x >> 6] = tally;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t4 = (unsigned long long)s_tally[0] + s_tally[1] + s_tally[2] + s_tally[3];
+    if (t4) atomicAdd(a.index_accesses, t4);
+  }
 }
 
 }  // namespace sbwt
