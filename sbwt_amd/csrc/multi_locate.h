@@ -1470,6 +1470,9 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
       }
       n_ev[kk] = keep;
     }
+#ifdef SBWT_PHASE_CLOCKS
+    team_sync<T>();  // (so that the prune phase is the slowest thread's, not thread 0's)
+#endif
     SBWT_PHASE_MEM(1);
     // ---- entries: numbered thread by thread, i.e. in row order
     uint32_t H;
