@@ -48,7 +48,9 @@ typedef struct sbwt_read_result {
   uint32_t flags;        /* SBWT_RF_* */
 } sbwt_read_result;
 #define SBWT_RF_SUPPRESSED 1u /* raw interval larger than `limit` (searcher.hpp:415) */
-#define SBWT_RF_TRUNCATED 2u  /* more pushes than raw interval size: only possible on an index that violates the k-ordering contract */
+#define SBWT_RF_TRUNCATED 2u  /* the list was cut at the raw interval size: it is longer (upstream's walk can report a row twice where a read
+                               * of L bases has L + interval - 1 beyond the depth the index's suffix order is sorted to; such lists are
+                               * reported whole, in slots behind all others) AND does not fit the record (16 bits of NH in 16 bytes) */
 
 /* Compact per-read result (sbwt_map_batch_device_compact / sbwt_map_batch_compact): everything start_sbwt_match
  * yields for a read in 16 bytes, the unique hit included, so that a read costs one quarter of a 64-byte write and

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
 
     bool missed = false;    // looked up and not in the table: the general kernels need not look again
     bool need_line = false; // second access: the PosLine of the position the read ends on
-    uint64_t pfin = 0;
+    uint64_t pfin = 0, run_fin = 0;  // run_fin: LF-consistent positions from pfin down (as far as the slot's field counts)
     if (look) {
       uint64_t pos = (slot >> 24) & kHashPosMask, run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
       const bool twin = slot != ~0ull && (slot & kHashTwin) != 0;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
           } else if (diff == 0) {
             need_line = true;
             pfin = pos - rem;
+            run_fin = run - rem;
           } else if (a.hits_only) {
             e1 = (uint64_t)R_NOSA << 56;
             pending = false;
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(256) void k_direct(const DeviceIndex ix, const Sett
             chr_id = h.chr_id;
             meta |= R_NH | (h.is_rc ? R_RC : 0u);
             fits = chr_id <= a.ring_chr_max && payload <= kPosMask;
+          } else if (walk_may_go_on(ix, pfin, run_fin)) {
+            fits = false;  // (rank_device.h: the general kernels)
           }
         }
         if (fits) {  // (a result no record holds stays pending: the general kernels own the wide path)

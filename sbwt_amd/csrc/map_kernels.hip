@@ -59,6 +59,7 @@ struct MapArgs {
   ResultIO io;
   sbwt_hit* hits;
   uint64_t hits_cap;
+  uint64_t multi_base;  // first slot of hits[] for the lists of multi-hit reads
   Counters* ctr;
   uint32_t* multi_queue;
 };
@@ -108,6 +109,31 @@ __device__ __forceinline__ bool scan_sampled(MultiState& S, uint64_t f, uint64_t
   return false;
 }
 
+// start_sbwt_match's locate (searcher.hpp:424-449) for the rows [lo, hi): level 0, then find_possible (searcher.hpp:460-503)
+// with the recursion unrolled onto an explicit stack (frames 1 .. interval-1)
+__device__ __forceinline__ void multi_walk(const DeviceIndex& ix, MultiState& S, Frame* stack, uint64_t lo, uint64_t hi) {
+  // VARS.maybe_result_number is an int compared against a size_t (searcher.hpp:412,464)
+  const uint64_t maybe = (uint64_t)(int64_t)(int32_t)(uint32_t)(hi - lo);
+  // level 0 (searcher.hpp:424-443); its break leaves a loop over ONE row after that row
+  scan_sampled(S, lo, hi, 0, false);
+  uint32_t d = 1;
+  stack[1].pf = lo; stack[1].pe = hi; stack[1].next_c = 0;
+  while (d >= 1) {
+    Frame& f = stack[d];
+    if (f.next_c == 4) { --d; continue; }
+    const uint32_t c = f.next_c++;
+    if ((uint64_t)d >= ix.interval) continue;
+    if (S.nres == maybe) continue;
+    const uint64_t nf = lf1(ix, f.pf, c), ne = lf1(ix, f.pe, c);
+    if (nf >= ne) continue;
+    if (scan_sampled(S, nf, ne, d, true)) continue;
+    if ((uint64_t)d + 1 < ix.interval) {  // a deeper call would return at once (len >= interval)
+      ++d;
+      stack[d].pf = nf; stack[d].pe = ne; stack[d].next_c = 0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapArgs a, Frame* __restrict__ stacks,
                                                uint32_t lanes_total, const uint32_t* __restrict__ queue,
                                                const unsigned long long* __restrict__ queue_count) {
@@ -127,28 +153,21 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
     S.L = a.lens[r];
     S.strand = a.strand;
     S.truncated = 0;
-    // VARS.maybe_result_number is an int compared against a size_t (searcher.hpp:412,464)
-    const uint64_t maybe = (uint64_t)(int64_t)(int32_t)(uint32_t)(hi - lo);
-    // level 0 (searcher.hpp:424-443); the break there needs an interval of size 1, never the case here
-    scan_sampled(S, lo, hi, 0, false);
-    // find_possible (searcher.hpp:460-503), recursion unrolled onto an explicit stack
-    uint32_t d = 1;
-    stack[1].pf = lo; stack[1].pe = hi; stack[1].next_c = 0;
-    while (d >= 1) {
-      Frame& f = stack[d];
-      if (f.next_c == 4) { --d; continue; }
-      const uint32_t c = f.next_c++;
-      if ((uint64_t)d >= ix.interval) continue;
-      if (S.nres == maybe) continue;
-      const uint64_t nf = lf1(ix, f.pf, c), ne = lf1(ix, f.pe, c);
-      if (nf >= ne) continue;
-      if (scan_sampled(S, nf, ne, d, true)) continue;
-      if ((uint64_t)d + 1 < ix.interval) {  // a deeper call would return at once (len >= interval)
-        ++d;
-        stack[d].pf = nf; stack[d].pe = ne; stack[d].next_c = 0;
+    multi_walk(ix, S, stack, lo, hi);
+    uint64_t first = res.first_hit;
+    if (S.truncated && list_fits_record(a.io, r, S.nres)) {
+      // more hits than rows (multi_locate.h, extra_slots): the walk again, into room of its own
+      const uint64_t e = extra_slots(&a.ctr->hit_count, &a.ctr->overflow, a.multi_base, a.hits_cap, S.nres);
+      if (e != ~0ull) {
+        first = e;
+        S.out = a.hits + e;
+        S.cap = S.nres;
+        S.nres = 0;
+        S.truncated = 0;
+        multi_walk(ix, S, stack, lo, hi);
       }
     }
-    rio_store_multi(a.io, r, res.first_hit, true, (int32_t)(S.nres < S.cap ? S.nres : S.cap), S.truncated ? SBWT_RF_TRUNCATED : 0u);
+    rio_store_multi(a.io, r, first, true, (int32_t)(S.nres < S.cap ? S.nres : S.cap), S.truncated ? SBWT_RF_TRUNCATED : 0u);
     atomicAdd(&a.ctr->rows_located, (unsigned long long)(hi - lo));  // (the few reads nothing else took)
   }
 }
@@ -491,6 +510,7 @@ static int pass_search(const sbwt_index* ix, const MapWork& w, const uint32_t* d
   a.io = io;
   a.hits = d_hits;
   a.hits_cap = hits_cap;
+  a.multi_base = multi_base;
   a.ctr = w.d_ctr;
   a.multi_queue = w.d_queue;
   SBWT_HIP(hipMemsetAsync(w.d_ctr, 0, sizeof(Counters), w.stream));
@@ -556,6 +576,9 @@ static int pass_search(const sbwt_index* ix, const MapWork& w, const uint32_t* d
     ms.chunk = 0;  // pass_multi
     ms.queue_count = &w.d_ctr->multi_count;
     ms.overflow = &w.d_ctr->overflow;
+    ms.hit_count = &w.d_ctr->hit_count;
+    ms.overflow_flag = &w.d_ctr->overflow;
+    ms.hits_cap = hits_cap;
     ms.dfs_queue = w.d_dfs_queue;
     ms.dfs_count = &w.d_ctr->dfs_count;
     ms.lds_tables = w.sort_lds_bytes ? 1u : 0u;

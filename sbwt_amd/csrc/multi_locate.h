@@ -90,6 +90,9 @@ struct MultiSortArgs {
   uint64_t chunk;
   const unsigned long long* queue_count; // total number of queued reads (k_multi_plan)
   const unsigned int* overflow;          // set by k_multi_plan when the hit slots do not fit hits_cap
+  unsigned long long* hit_count;         // slots handed out behind multi_base, and the flag above to write, and the room: extra_slots
+  unsigned int* overflow_flag;
+  uint64_t hits_cap;
   uint32_t lds_tables;                   // the launch carries (n_chr + 2 n_npos) * 8 bytes of dynamic LDS for the filter tables
   uint32_t* dfs_queue;                   // reads this kernel hands on to k_multi
   unsigned long long* dfs_count;
@@ -99,6 +102,26 @@ struct MultiSortArgs {
   unsigned long long* rows_count;        // raw rows of the reads the locate kernels located themselves (measurement: a shared list counts once)
   uint32_t no_segments;                  // wave teams take one read at a time whatever its size (SBWT_NO_SEGMENTS: measurement and tests)
 };
+
+// Room for a list that is longer than its read has rows.  On tables whose suffix order has unordered ties, a read of L
+// bases with L + interval - 1 beyond the depth that order vouches for can surface one chain twice (multi_locate.h top);
+// the search kernels reserved one slot per row.  n slots behind everything handed out so far; ~0: hits[] has no room
+// (the batch fails with SBWT_ERR_CAPACITY, and the count the caller is told includes this list).
+__device__ __forceinline__ uint64_t extra_slots(unsigned long long* hit_count, unsigned int* overflow, uint64_t multi_base,
+                                                uint64_t hits_cap, uint64_t n) {
+  const uint64_t off = atomicAdd(hit_count, (unsigned long long)n);
+  if (multi_base + off + n > hits_cap) {
+    atomicExch(overflow, 1u);
+    return ~0ull;
+  }
+  return multi_base + off;
+}
+// does read r's record hold a list of n hits?  (a 16-byte record has 16 bits for NH)
+__device__ __forceinline__ bool list_fits_record(const ResultIO& io, uint64_t r, uint64_t n) {
+  if (!io.compact) return n <= 0x7FFFFFFFull;
+  if ((uint32_t)(io.compact[r].w1 >> 56) & SBWT_CR_WIDE) return n <= 0x7FFFFFFFull;
+  return n <= 0xFFFFull;
+}
 
 // Turns the per-wave totals of k_search_sm into global offsets: exclusive prefix sums of the hit slots and of the
 // queued reads over waves, the grand totals, and the capacity verdict.  One workgroup.
@@ -528,6 +551,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
   __shared__ uint64_t s_red_all[4][4];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_cnt_all[kTeams][4];  // hits, nodes of the next level, overflow, cut
+  __shared__ unsigned long long s_extra[kTeams];  // extra_slots of the read at hand
   // workgroup teams: children of more than kBigRows rows are scanned by a whole wave (a lane per 64-row block), not by
   // the thread that made them -- on tie-shuffled tables the copies of a repeat stay in ONE node level after level
   constexpr uint32_t kBigRows = 128, kBigMax = 16;
@@ -797,10 +821,17 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     team_sync<T>();
     const uint32_t cut = cnt[3];
     const uint32_t nres = cut < H ? (uint32_t)acc_of[cut] : base;
-    sbwt_hit* out = a.hits + res.first_hit;
+    uint64_t first = res.first_hit;
+    uint32_t room = (uint32_t)m;
+    if ((uint64_t)nres > m) {  // more hits than rows (extra_slots above): the list goes behind everything else
+      if (tid == 0) s_extra[team] = list_fits_record(a.io, r, nres) ? extra_slots(a.hit_count, a.overflow_flag, a.multi_base, a.hits_cap, nres) : ~0ull;
+      team_sync<T>();
+      if (s_extra[team] != ~0ull) { first = s_extra[team]; room = nres; }
+    }
+    sbwt_hit* out = a.hits + first;
     for (uint32_t k = tid; k < cut; k += T) {
       const uint64_t py = pay[idx_of[k]];
-      if ((py & kPayOk) && (uint64_t)acc_of[k] < m) {
+      if ((py & kPayOk) && (uint32_t)acc_of[k] < room) {
         sbwt_hit h;
         h.pos0 = py & kPosMask;
         h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
@@ -809,7 +840,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
       }
     }
     if (tid == 0) {
-      rio_store_multi(a.io, r, res.first_hit, true, (int32_t)((uint64_t)nres < m ? nres : (uint32_t)m), (uint64_t)nres > m ? SBWT_RF_TRUNCATED : 0u);
+      rio_store_multi(a.io, r, first, true, (int32_t)(nres < room ? nres : room), nres > room ? SBWT_RF_TRUNCATED : 0u);
       queue[q] = kQueueDone;
       atomicAdd(a.bfs_count, 1ull);
       atomicAdd(a.rows_count, (unsigned long long)m);
@@ -1293,6 +1324,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
   __shared__ uint64_t s_red_all[4][4];
   __shared__ uint32_t s_scan_all[4];
   __shared__ uint32_t s_cnt_all[kTeams][4];  // [0] fail, [1] cut
+  __shared__ unsigned long long s_extra[kTeams];  // extra_slots of the read at hand
   extern __shared__ __attribute__((aligned(16))) uint64_t s_tab[];
   if (*a.overflow) return;
   if (!ix.chain_tab || ix.interval > 64 || ix.n_chr > 0xFFFFu) return;
@@ -1577,10 +1609,17 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     team_sync<T>();
     const uint32_t cut = cnt[1];
     const uint32_t nres = cut < H ? (uint32_t)acc_of[cut] : base;
-    sbwt_hit* out = a.hits + res.first_hit;
+    uint64_t first = res.first_hit;
+    uint32_t room = m;
+    if (nres > m) {  // more hits than rows (extra_slots): the list goes behind everything else
+      if (tid == 0) s_extra[team] = list_fits_record(a.io, r, nres) ? extra_slots(a.hit_count, a.overflow_flag, a.multi_base, a.hits_cap, nres) : ~0ull;
+      team_sync<T>();
+      if (s_extra[team] != ~0ull) { first = s_extra[team]; room = nres; }
+    }
+    sbwt_hit* out = a.hits + first;
     for (uint32_t k = tid; k < cut; k += T) {
       const uint64_t py = pay[sorted.ord[k]];
-      if ((py & kPayOk) && (uint32_t)acc_of[k] < m) {
+      if ((py & kPayOk) && (uint32_t)acc_of[k] < room) {
         sbwt_hit h;
         h.pos0 = py & kPosMask;
         h.chr_id = (uint32_t)(py >> kPosBits) & 0xFFFFu;
@@ -1589,7 +1628,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
       }
     }
     if (tid == 0) {
-      rio_store_multi(a.io, r, res.first_hit, true, (int32_t)(nres < m ? nres : m), nres > m ? SBWT_RF_TRUNCATED : 0u);
+      rio_store_multi(a.io, r, first, true, (int32_t)(nres < room ? nres : room), nres > room ? SBWT_RF_TRUNCATED : 0u);
       queue[q] = kQueueDone;
       rows_done += m;
       ++reads_done;

@@ -163,6 +163,16 @@ __device__ __forceinline__ bool push_position_keys(const DeviceIndex& ix, const 
   const uint32_t n1 = upper_bound_minus1(npos_key, ix.n_npos, position);
   return push_position_finish(ix, chr, npos_key, npos_val, position, L, is_rc, c1, n1, out);
 }
+// A ONE-row interval whose position the filters drop (searcher.hpp:516-533).  Upstream's walk goes on below that row
+// when the row was sampled itself: the break of searcher.hpp:440 leaves only the loop, and find_possible runs while the
+// result is empty (searcher.hpp:446-449, 464).  Where the positions below p are LF-consistent over the sampling distance
+// (`run` of them: device_index.hip, k_verify_rows) the walk meets no second sampled row before it gives up
+// (searcher.hpp:462); on tables with unordered ties it can, and then reports THAT position: such a read takes the
+// depth-first locate like a multi-hit read (one row, one slot).
+__device__ __forceinline__ bool walk_may_go_on(const DeviceIndex& ix, uint64_t p, uint64_t run) {
+  const uint64_t need = p + 1 < ix.interval ? p + 1 : ix.interval;
+  return run < need;
+}
 __device__ __forceinline__ bool push_position_lane(const DeviceIndex& ix, uint64_t position, uint32_t L, int strand,
                                                    sbwt_hit* out) {
   return push_position_keys(ix, ix.chr_start, ix.npos_key, ix.npos_val, position, L, strand, out);

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
     uint64_t lo = 0, hi = 0, p = 0;
     uint32_t j = j0;
     bool cmp = false;  // p holds the position the one row left reports; bases [j, L) remain
+    uint64_t run_fin = 0;  // LF-consistent positions from the read's last position down (as far as the entry's field counts)
     {
       const uint64_t cw = ~w_lo;  // complemented codes of bases 0..31
       uint64_t ent = 0;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
         if (ent & kKmerLocated) {
           const uint64_t pos = ent & kPosMask, run = (ent >> kPosBits) & kKmerRunMax;
           const uint64_t rem = (uint64_t)L - K;
-          if (rem >= 1 && run > rem && pos >= rem) { p = pos; cmp = true; lo = 0; hi = 1; }
+          if (rem >= 1 && run > rem && pos >= rem) { p = pos; run_fin = run - rem; cmp = true; lo = 0; hi = 1; }
           else go = false;
         } else if (width == kKmerWide) {
           go = false;  // (not memoised: the pair; rare -- left to the general kernels)
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
         ++lines_n;
         const uint64_t pos = e & kPosMask, run = e >> kPosBits;
         const uint32_t rem = L - j;
-        if (e != kNoPosition && run > (uint64_t)rem && pos >= (uint64_t)rem) { p = pos; cmp = true; }
+        if (e != kNoPosition && run > (uint64_t)rem && pos >= (uint64_t)rem) { p = pos; run_fin = run - rem; cmp = true; }
         else go = false;
       } else {
         go = false;  // several rows at the end of the read, one base left on a wide interval, a row at the very end: general kernels
@@ -315,6 +316,8 @@ __global__ __launch_bounds__(256) void k_rank(const DeviceIndex ix, const Settle
             chr_id = h.chr_id;
             meta |= R_NH | (h.is_rc ? R_RC : 0u);
             fits = chr_id <= a.ring_chr_max && payload <= kPosMask;
+          } else if (walk_may_go_on(ix, pfin, run_fin)) {
+            fits = false;  // (rank_device.h: the general kernels)
           }
         }
         if (fits) {  // (a result no record holds stays pending: the general kernels own the wide path)

@@ -256,6 +256,8 @@ constexpr uint32_t A_CUR_KH = 1u << 22;   // ... which came from hash_tab: a loc
 constexpr uint32_t A_CUR_P2 = 1u << 23;   // (long-read variant) w2 holds the 64-base piece after the one in w
 constexpr uint32_t A_REQ_P2 = 1u << 25;   // (long-read variant) ... and is on its way with the next piece
 constexpr uint32_t A_DIRECT = 1u << 24;   // the prefix entry was a located row: next state is the text comparison
+constexpr uint32_t A_RUN_SEEN = 1u << 26; // S_LOCATE has seen sa_full of the final row: A_LOOSE is valid
+constexpr uint32_t A_LOOSE = 1u << 27;    // ... and the positions below it are not LF-consistent over the sampling distance (walk_may_go_on)
 
 // prefetch pipeline of a lane: its next read (1) and the one after (2)
 constexpr uint32_t PF_W1 = 1u, PF_K1 = 2u, PF_W2 = 4u;        // record of 1, prefix entry of 1, record of 2 are here
@@ -904,7 +906,8 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
       case S_LOCATE: {
         p = vc & kPosMask;
         if (vc == kNoPosition) aux |= A_NOPOS;  // the upstream locate finds nothing
-        aux |= A_LOCATED;
+        else if (walk_may_go_on(ix, p, vc >> kPosBits)) aux |= A_LOOSE;
+        aux |= A_LOCATED | A_RUN_SEEN;
         finish = true;
         break;
       }
@@ -921,9 +924,23 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
       st = S_LOCATE;
       finish = false;
     }
+    // one row: its position through the filters (searcher.hpp:504-539).  A position they drop, on a row below which the
+    // tables are not LF-consistent over the sampling distance: upstream's walk may surface again (rank_device.h,
+    // walk_may_go_on) -- the read is located like a multi-hit read.  (A position that came out of a text comparison: S_LOCATE
+    // looks at the final row first.)
+    sbwt_hit h1;
+    bool passes = false;
+    if (finish && m == 1 && m <= a.limit && !(aux & A_NOPOS)) {
+      passes = push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h1);
+      if (!passes && !(aux & A_RUN_SEEN)) {
+        st = S_LOCATE;
+        finish = false;
+      }
+    }
+    const bool walk1 = finish && m == 1 && m <= a.limit && !passes && (aux & A_LOOSE);
     // multi-hit reads take hit slots (numbered within the wave; k_multi_plan makes them global) and a queue entry
     // in the wave's own stretch of the queue
-    const uint64_t want = (finish && m > 1 && m <= a.limit) ? m : 0;
+    const uint64_t want = (finish && (m > 1 || walk1) && m <= a.limit) ? m : 0;
     uint64_t multi_off = 0;
     const uint64_t mm = __ballot(want != 0);
     if (mm) {
@@ -947,16 +964,13 @@ __global__ __launch_bounds__(256, 4) void k_search_sm(const DeviceIndex ix, cons
       uint32_t chr_id = 0;
       if (m > a.limit) {
         flags |= SBWT_RF_SUPPRESSED;
-      } else if (m == 1) {
-        sbwt_hit h;
-        if (!(aux & A_NOPOS) && push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h)) {
-          payload = h.pos0;
-          chr_id = h.chr_id;
-          meta = R_NH | (h.is_rc ? R_RC : 0u);
-        }
       } else if (want) {
         payload = multi_off;  // first slot, wave-relative until k_multi_sort adds the wave's base
         meta = R_MULTI;
+      } else if (passes) {
+        payload = h1.pos0;
+        chr_id = h1.chr_id;
+        meta = R_NH | (h1.is_rc ? R_RC : 0u);
       }
       // flags: bits 0..1 and bit 31 are in use
       meta |= ((flags & 3u) << R_FLAGS_SHIFT) | ((flags & kFlagInvalid) ? R_INVALID : 0u);

@@ -378,7 +378,22 @@ __global__ __launch_bounds__(256) void k_search_rounds(const DeviceIndex ix, con
 
     // ---- the batch is through: suppression (searcher.hpp:415), filters, multi-hit slots, records (as k_search_sm)
     const uint64_t m = valid && hi > lo ? hi - lo : 0;
-    const uint64_t want = (valid && m > 1 && m <= a.limit) ? m : 0;
+    // one row: its position through the filters (searcher.hpp:504-539).  A position they drop, on a row below which the
+    // tables are not LF-consistent over the sampling distance: upstream's walk may surface again (rank_device.h,
+    // walk_may_go_on) -- the read is located like a multi-hit read
+    sbwt_hit h1;
+    const bool one_row = valid && m == 1 && m <= a.limit && !nopos;
+    const bool passes = one_row && push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h1);
+    bool walk1 = false;
+    const bool dropped = one_row && !passes;
+    if (__any(dropped)) {
+      if (dropped) {
+        const uint64_t e = ix.sa_full[lo];
+        ++tally;
+        walk1 = e != kNoPosition && walk_may_go_on(ix, e & kPosMask, e >> kPosBits);
+      }
+    }
+    const uint64_t want = (valid && (m > 1 || walk1) && m <= a.limit) ? m : 0;
     uint64_t multi_off = 0;
     const uint64_t mm = __ballot(want != 0);
     if (mm) {
@@ -402,16 +417,13 @@ __global__ __launch_bounds__(256) void k_search_rounds(const DeviceIndex ix, con
       uint32_t chr_id = 0;
       if (m > a.limit) {
         flags |= SBWT_RF_SUPPRESSED;
-      } else if (m == 1) {
-        sbwt_hit h;
-        if (!nopos && push_position_keys(ix, T.chr, T.npos_key, T.npos_val, p, L, a.strand, &h)) {
-          payload = h.pos0;
-          chr_id = h.chr_id;
-          meta = R_NH | (h.is_rc ? R_RC : 0u);
-        }
       } else if (want) {
         payload = multi_off;  // first slot, wave-relative until k_multi_sort adds the wave's base
         meta = R_MULTI;
+      } else if (passes) {
+        payload = h1.pos0;
+        chr_id = h1.chr_id;
+        meta = R_NH | (h1.is_rc ? R_RC : 0u);
       }
       meta |= ((flags & 3u) << R_FLAGS_SHIFT) | ((flags & kFlagInvalid) ? R_INVALID : 0u);
       uint64_t width = hi - lo;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
     bool missed = false;  // looked up and not in the table as a located prefix: the general kernels need not look again
     if (look) {
       uint64_t pos = (slot >> 24) & kHashPosMask;
-      const uint64_t run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
+      uint64_t run = (slot & 0xFFFFFFull) >> ix.hash_tag_bits;
       const bool twin = slot != ~0ull && (slot & kHashTwin) != 0;
       // (run 0: a marker -- the prefix occurs, on several rows or on one not located; so does a twin without its partner)
       missed = slot == ~0ull || run == 0 || (twin && (slot2 == ~0ull || !(slot2 & kHashTwin)));
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
           const uint64_t pos2 = (slot2 >> 24) & kHashPosMask, run2 = (slot2 & 0xFFFFFFull) >> ix.hash_tag_bits;
           const uint64_t diff2 = (r0 ^ text2) & cmask;
           usable = usable && run2 > (uint64_t)rem && pos2 >= (uint64_t)rem && (diff != 0 || diff2 != 0);  // (both: two hits, not here)
-          if (diff != 0 && diff2 == 0) { pos = pos2; diff = 0; }
+          if (diff != 0 && diff2 == 0) { pos = pos2; run = run2; diff = 0; }
         }
         if (usable) {
           uint32_t meta = R_NOSA;
@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void k_settle(const DeviceIndex ix, const Sett
                 chr_id = h.chr_id;
                 meta |= R_NH | (h.is_rc ? R_RC : 0u);
                 fits = chr_id <= a.ring_chr_max && payload <= kPosMask;
+              } else if (walk_may_go_on(ix, pos - rem, run - rem)) {
+                fits = false;  // (rank_device.h: the general kernels; `run` stops counting at its field's width: more reads, no fewer)
               }
             }
           }

@@ -32,7 +32,7 @@ BUILD_KNOBS = {
     "SBWT_NO_TWINS": [None, None, None, "1"],
     "SBWT_NO_CHAIN_TAB": [None, None, None, None, "1"],
     "SBWT_NO_HASH_COMPLETE": [None, None, None, None, "1"],
-    "SBWT_DEBUG_SORT_DEPTH": [None, None, "54", "108", "256"],
+    "SBWT_DEBUG_SORT_DEPTH": [None, None, "27", "54", "108", "256"],
 }
 PASS_KNOBS = {
     "SBWT_NO_SETTLE": [None] * 6 + ["1"],
@@ -268,6 +268,7 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
         t0 = time.time()
         lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand, nthreads=8)
         t_oracle = time.time() - t0
+        over = int((nh.astype(np.int64) > (hi.astype(np.int64) - lo.astype(np.int64))).sum())
         with Env({**build_env, **pass_env}):
             ctx = sb.Context(ix, len(reads))
         try:
@@ -284,16 +285,16 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
         finally:
             ctx.close()
         if verbose:
-            print("%s | hash %d text %d | nh>1 %d, nh>64 %d, max nh %d, dead %d | build %.1f s, oracle %.1f s | %s" % (
+            print("%s | hash %d text %d | nh>1 %d, nh>64 %d, max nh %d, dead %d, lists longer than the interval %d | build %.1f s, oracle %.1f s | %s" % (
                 desc, ix.info().hash_order, ix.info().hash_text, (nh > 1).sum(), (nh > 64).sum(), nh.max(), (nh == 0).sum(),
-                t_build, t_oracle, "ok" if not problems else "MISMATCH"), flush=True)
+                over, t_build, t_oracle, "ok" if not problems else "MISMATCH"), flush=True)
             for p_ in problems:
                 print("    " + p_, flush=True)
     finally:
         oix.close()
         ix.close()
         sb.host_tables_free(tables)
-    return problems, desc
+    return problems, desc + " | lists longer than the interval: %d" % over
 
 
 def main():

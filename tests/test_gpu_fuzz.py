@@ -13,3 +13,22 @@ def test_fuzz_seed(oracle, seed):
     sb.device_count()
     problems, desc = fuzz_parity.run_seed(seed, sb, oracle, n_reads=8000, verbose=False)
     assert not problems, desc + "\n" + "\n".join(problems)
+
+
+@pytest.mark.parametrize("seed,lists_longer", [(34, True), (49, True), (110, True), (120, True), (37, False), (46, False),
+                                               (78, False), (143, False)])
+def test_fuzz_seed_beyond_the_sort_depth(oracle, seed, lists_longer):
+    """Reads of L bases on an index whose suffix order stops before L + interval - 1 bases (upstream's builder stops at
+    sort_len 256: reads of 194 bases and more).  Upstream's depth-first locate then reports a row every time its chain
+    meets a sampled row -- more hits than the interval has rows (searcher.hpp:464 compares with ==, and the count can jump
+    over it), and a one-row interval whose first position the filters drop goes on to a second one (searcher.hpp:440 breaks
+    the loop only).  The library reports the same lists: the longer ones in slots behind all others (seeds 34, 49, 110,
+    120: through k_multi_chain, k_multi_bfs and k_multi), the one-row reads through the depth-first locate (the others;
+    each of these seeds failed before that)."""
+    import sbwt_amd as sb
+    import fuzz_parity
+    sb.device_count()
+    problems, desc = fuzz_parity.run_seed(seed, sb, oracle, n_reads=12000, verbose=False, beyond=True)
+    assert not problems, desc + "\n" + "\n".join(problems)
+    if lists_longer:
+        assert not desc.endswith(": 0"), desc
