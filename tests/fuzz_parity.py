@@ -7,7 +7,8 @@ duplications, which are the tie groups of a depth-limited suffix order; random c
 built on the GPU under a random choice of the build knobs (prefix-table orders, slot text, twins, chain_tab, suffix
 order stopped at 27 / 54 / 256 bases, SA sampling interval), one context under a random choice of the pass knobs, one
 batch of reads (substrings of both strands with and without a substitution, reads inside the families, reads across
-chromosome and N-run boundaries, reads at the text ends, random and low-complexity reads; lengths 12 .. 200) mapped
+chromosome and N-run boundaries, reads at the text ends, random and low-complexity reads; lengths 12 .. 200, and from
+seed 100000 on up to 512) mapped
 through the 32-byte records, the compact records and hits-only, for a random -m limit and strand choice.  What is
 compared is what start_sbwt_match (searcher.hpp:386-539) produces: SA interval, NH, and the ordered hit list of every
 read.
@@ -114,10 +115,12 @@ def make_genome(rng):
     return codes, fams, chr_start, keys, vals
 
 
-def make_reads(rng, codes, fams, chr_start, keys, n, l_max=200):
+def make_reads(rng, codes, fams, chr_start, keys, n, l_max=512, wide=False):
     g = len(codes)
     lens_pool = [list(range(12, 34)), [18, 22, 26, 30], [36], [50], [36, 50, 51, 52, 53, 64], [65, 100, 128], [100],
                  [129, 150, 192, 200], list(range(12, 201, 7))]
+    if wide:  # (seeds from 100000 on: the draws of the earlier seeds stay what they were)
+        lens_pool += [[12, 13, 14, 15, 16, 40], [200, 256, 257, 300, 384, 385, 512], [30, 64, 65, 128, 129, 192, 193, 320]]
     lens_ = lens_pool[int(rng.integers(0, len(lens_pool)))]
     lens_ = sorted(set(min(x, l_max) for x in lens_))
     mutate = float(rng.choice([0.0, 0.2, 0.5]))
@@ -230,14 +233,14 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
     # locate extends a read of L bases by up to interval - 1 more: L + interval - 1 <= k.  (Beyond it upstream's walk
     # reports rows twice or not at all; the library follows it up to the raw interval size and flags the rest
     # SBWT_RF_TRUNCATED, include/sbwt_amd.h.)  `beyond` lifts the restriction.
-    l_max = 200
+    l_max = 512
     if "SBWT_DEBUG_SORT_DEPTH" in build_env and not beyond:
         k_ord = (int(build_env["SBWT_DEBUG_SORT_DEPTH"]) + 26) // 27 * 27
-        l_max = min(200, k_ord - interval + 1)
+        l_max = min(512, k_ord - interval + 1)
         if l_max < 12:
             build_env.pop("SBWT_DEBUG_SORT_DEPTH")
-            l_max = 200
-    limit = int(rng.choice([1000, 1000, 1000, 0, 1, 7, 300, 5000]))
+            l_max = 512
+    limit = int(rng.choice([1000, 1000, 1000, 0, 1, 7, 300, 5000] + ([-1] if seed >= 100000 else [])))
     strand = int(rng.choice([2, 2, 2, 0, 1]))
     desc = "seed %d: g %d, interval %d, -m %d, strand %d, reads <= %d, build %s, pass %s" % (seed, g, interval, limit, strand, l_max, build_env, pass_env)
     hip = C.CDLL("libamdhip64.so.7")
@@ -263,7 +266,7 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
     oix = oracle.OracleIndex(h, keep=(c4, chr_start, keys, vals))
     problems = []
     try:
-        reads = make_reads(rng, codes, fams, chr_start, keys, n_reads, l_max)
+        reads = make_reads(rng, codes, fams, chr_start, keys, n_reads, l_max, wide=seed >= 100000)
         packed, lens = sb.pack_reads(reads)
         t0 = time.time()
         lo, hi, nh, first, ohits = oix.map_batch(reads, limit=limit, strand=strand, nthreads=8)
@@ -284,6 +287,32 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
                 problems += compare(tag, res, hits, lo, hi, nh, first, ohits, sa_mask=~no_sa)
         finally:
             ctx.close()
+        if seed >= 100000:
+            # the host pipeline on the same reads: FASTQ in, SAM out (sbwt_map_fastq; position2sam, sam.hpp), bytes and
+            # counters against the oracle's; random batch size and formatter threads
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                fq, sam_a, sam_b = os.path.join(td, "r.fq"), os.path.join(td, "a.sam"), os.path.join(td, "b.sam")
+                sub = reads[: int(rng.choice([1, 700, 4000]))]
+                with open(fq, "wb") as f:
+                    for k, s_ in enumerate(sub):
+                        q = bytes(33 + (k + j) % 41 for j in range(len(s_)))
+                        f.write(b"@r%d\n%s\n+\n%s\n" % (k, s_, q))
+                env = {}
+                b_ = rng.choice(["", "64", "1000"])
+                if b_:
+                    env["SBWT_FASTQ_BATCH"] = str(b_)
+                nt = int(rng.choice([1, 2, 5, 16]))
+                with Env({**build_env, **pass_env, **env}):
+                    st = ix.map_fastq(fq, sam_a, limit=limit, strand=strand, n_threads=nt)
+                rc, ost = oix.map_fastq(fq, sam_b, limit=limit, strand=strand)
+                if rc != 0 or list(st) != list(ost):
+                    problems.append("map_fastq: counters %s, oracle rc %d %s" % (list(st), rc, list(ost)))
+                elif open(sam_a, "rb").read() != open(sam_b, "rb").read():
+                    la, lb = open(sam_a, "rb").read().split(b"\n"), open(sam_b, "rb").read().split(b"\n")
+                    k = next((i for i, (x, y) in enumerate(zip(la, lb)) if x != y), min(len(la), len(lb)))
+                    problems.append("map_fastq (%d reads, %d threads, batch %s): SAM line %d differs: %r, oracle %r"
+                                    % (len(sub), nt, b_ or "default", k, la[k][:200] if k < len(la) else None, lb[k][:200] if k < len(lb) else None))
         if verbose:
             print("%s | hash %d text %d | nh>1 %d, nh>64 %d, max nh %d, dead %d, lists longer than the interval %d | build %.1f s, oracle %.1f s | %s" % (
                 desc, ix.info().hash_order, ix.info().hash_text, (nh > 1).sum(), (nh > 64).sum(), nh.max(), (nh == 0).sum(),
