@@ -32,3 +32,15 @@ def test_fuzz_seed_beyond_the_sort_depth(oracle, seed, lists_longer):
     assert not problems, desc + "\n" + "\n".join(problems)
     if lists_longer:
         assert not desc.endswith(": 0"), desc
+
+
+@pytest.mark.parametrize("seed", [0, 1, 5, 7, 11])
+def test_fuzz_builder_seed(oracle, seed):
+    """tests/fuzz_builder.py: a random FASTA through `sbwt build` on the GPU and through the oracle's builder -- the index
+    files byte for byte (a genome with a duplication longer than sort_len: the mapping only), then FASTQ -> SAM on the
+    GPU's files (400 seeds: profiles/r3/fuzz_builder_400.txt)"""
+    import sbwt_amd as sb
+    import fuzz_builder
+    sb.device_count()
+    problems, desc = fuzz_builder.run_seed(seed, sb, oracle, verbose=False)
+    assert not problems, desc + "\n" + "\n".join(problems)
