@@ -551,7 +551,9 @@ extern "C" int sbwt_map_fastq_multi(const sbwt_index* const* ixs, int n_ix, cons
         uint64_t cnt[2] = {0, 0};
         int r = sbwt_map_batch_compact(lanes[(size_t)d].ctx, S.packed.data() + a * S.wpr, S.lens.data() + a, b - a, S.wpr, limit, strand,
                                        SBWT_MAP_HITS_ONLY, S.out.data() + a, O.lists.data(), O.lists.cap, O.wide.data(), O.wide.cap, cnt);
-        if (r == SBWT_ERR_CAPACITY) {  // lists or wide records did not fit: once more with what it asked for
+        // lists or wide records did not fit: again with what it asked for (a second time when the first count could not
+        // yet include the lists that are longer than their intervals: multi_locate.h, extra_slots)
+        for (int tries = 0; r == SBWT_ERR_CAPACITY && tries < 4; ++tries) {
           if (O.lists.ensure(cnt[0] + (cnt[0] >> 2) + 16) || O.wide.ensure(cnt[1] + 16)) { rcs[(size_t)d] = SBWT_ERR_NOMEM; errs[(size_t)d] = sbwt_last_error(); return; }
           r = sbwt_map_batch_compact(lanes[(size_t)d].ctx, S.packed.data() + a * S.wpr, S.lens.data() + a, b - a, S.wpr, limit, strand,
                                      SBWT_MAP_HITS_ONLY, S.out.data() + a, O.lists.data(), O.lists.cap, O.wide.data(), O.wide.cap, cnt);
