@@ -9,7 +9,9 @@ order stopped at 27 / 54 / 256 bases, SA sampling interval), one context under a
 batch of reads (substrings of both strands with and without a substitution, reads inside the families, reads across
 chromosome and N-run boundaries, reads at the text ends, random and low-complexity reads; lengths 12 .. 200, and from
 seed 100000 on up to 512) mapped
-through the 32-byte records, the compact records and hits-only, for a random -m limit and strand choice.  What is
+through the 32-byte records, the compact records and hits-only, for a random -m limit and strand choice (from seed
+200000 on also through sbwt_map_batch_device and sbwt_map_batch_device_static, from a hits buffer that is too small at
+first).  What is
 compared is what start_sbwt_match (searcher.hpp:386-539) produces: SA interval, NH, and the ordered hit list of every
 read.
 """
@@ -285,6 +287,48 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
                     problems.append("compact: %d records without an SA interval" % no_sa.sum())
                 res, hits = sb.compact_expand(rec, lists, wide)
                 problems += compare(tag, res, hits, lo, hi, nh, first, ohits, sa_mask=~no_sa)
+            if seed >= 200000:
+                # the device-pointer entry points on the same batch: sbwt_map_batch_device (the ctx's) and
+                # sbwt_map_batch_device_static (no ctx, allocates nothing), twice each with a capacity retry in between
+                res0, hits0 = ctx.map_batch(packed, lens, limit=limit, strand=strand)
+                n = len(reads)
+                wpr = packed.shape[1] if packed.ndim == 2 else packed.size // n
+                bufs = []
+
+                def dev(nbytes):
+                    p_ = C.c_void_p()
+                    assert hip.hipMalloc(C.byref(p_), max(int(nbytes), 16)) == 0
+                    bufs.append(p_)
+                    return p_
+
+                d_p, d_l = dev(packed.nbytes), dev(lens.nbytes)
+                assert hip.hipMemcpy(d_p, packed.ctypes.data, packed.nbytes, 1) == 0
+                assert hip.hipMemcpy(d_l, lens.ctypes.data, lens.nbytes, 1) == 0
+                d_r = dev(n * sb.api.RESULT_DTYPE.itemsize)
+                L_ = sb.api.lib()
+                for tag in ("device", "static"):
+                    cap = n  # too small whenever a list exists: the capacity report says what to come back with
+                    used = C.c_uint64(0)
+                    for _ in range(6):
+                        d_h = dev(cap * sb.api.HIT_DTYPE.itemsize)
+                        if tag == "device":
+                            rc_ = L_.sbwt_map_batch_device(ctx._h, d_p.value, d_l.value, n, wpr, limit, strand, d_r.value, d_h.value, cap, C.byref(used))
+                        else:
+                            rc_ = L_.sbwt_map_batch_device_static(ix._h, None, d_p.value, d_l.value, n, wpr, limit, strand, d_r.value, d_h.value, cap, C.byref(used))
+                        if rc_ != -7:
+                            break
+                        cap = int(used.value)
+                    if rc_ != 0:
+                        problems.append("%s: rc %d after capacity retries (%s)" % (tag, rc_, L_.sbwt_last_error().decode()))
+                        continue
+                    used = used.value
+                    res1 = np.zeros(n, dtype=sb.api.RESULT_DTYPE)
+                    hits1 = np.zeros(max(int(used), 1), dtype=sb.api.HIT_DTYPE)
+                    assert hip.hipMemcpy(res1.ctypes.data, d_r, res1.nbytes, 2) == 0
+                    assert hip.hipMemcpy(hits1.ctypes.data, d_h, int(used) * sb.api.HIT_DTYPE.itemsize, 2) == 0
+                    problems += compare(tag, res1, hits1, lo, hi, nh, first, ohits)
+                for b_ in bufs:
+                    hip.hipFree(b_)
         finally:
             ctx.close()
         if seed >= 100000:

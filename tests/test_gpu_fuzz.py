@@ -6,7 +6,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [3, 36, 54, 57, 101, 202, 303, 404, 100400, 100401, 100402, 100403])  # (from 100000 on: reads up to 512 bases, -m -1, FASTQ -> SAM)
+@pytest.mark.parametrize("seed", [3, 36, 54, 57, 101, 202, 303, 404, 100400, 100401, 100402, 100403,
+                                  200000, 200001, 200002])  # (from 100000 on: reads up to 512 bases, -m -1, FASTQ -> SAM; from 200000 on: the device-pointer entry points too)
 def test_fuzz_seed(oracle, seed):
     import sbwt_amd as sb
     import fuzz_parity
@@ -16,7 +17,7 @@ def test_fuzz_seed(oracle, seed):
 
 
 @pytest.mark.parametrize("seed,lists_longer", [(34, True), (49, True), (110, True), (120, True), (37, False), (46, False),
-                                               (78, False), (143, False), (100610, True), (100643, True)])
+                                               (78, False), (143, False), (100610, True), (100643, True), (200100, False), (200101, False)])
 def test_fuzz_seed_beyond_the_sort_depth(oracle, seed, lists_longer):
     """Reads of L bases on an index whose suffix order stops before L + interval - 1 bases (upstream's builder stops at
     sort_len 256: reads of 194 bases and more).  Upstream's depth-first locate then reports a row every time its chain
