@@ -1473,38 +1473,87 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     SBWT_PHASE_MEM(0);
     // ---- a node of one sampled row has no children: an event at depth d >= 1 in a node no other chain passes through
     // ends its chain (only chains with several events can lose any)
+    // The rows with several events go into a list, a thread per listed row: the rule is a chain of dependent LDS reads per
+    // event (the neighbours, nearest first), and a thread that walks through the events of its own four rows one after
+    // the other made the team wait 15,000 clocks a read for its slowest wave -- for 16 events a read.  A list entry =
+    // row | events << 10 | the depths of the events the rule looks at (all but the last; six bits each, eight at most).
+    {
+      uint64_t ev1[4], ev2[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const uint32_t i = 4u * tid + (uint32_t)kk;
-      if (n_ev[kk] < 2u) continue;
-      const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
-      uint32_t keep = n_ev[kk];
-      for (uint32_t j = 0; j + 1 < n_ev[kk]; ++j) {
-        const uint32_t d = (uint32_t)((j == 0 ? ev0[kk] : evs[j - 1]) >> 58);
-        if (d == 0) continue;  // (level 0, searcher.hpp:424-443, has no early return)
-        const ulonglong2 w = prefix_of(full[kk], d);
-        // (on an index that is k-ordered as far as the walk reaches there IS another chain through the node whenever this one
-        // has a later event -- a lone row would be a unique occurrence from here on -- and it is a row nearby: the copies
-        // the chain hops between share their right contexts too.  So: the neighbours first, and out at the first sharer.)
-        bool alone = true;
-        for (uint32_t dl = 1; dl < m && alone; ++dl) {
-          const uint32_t o1 = i + dl;
-          if (o1 < m && len_of[o1] >= d) {
-            const ulonglong2 v = prefix_of(kb[o1], d);
-            alone = v.x != w.x || v.y != w.y;
-          }
-          if (alone && i >= dl && len_of[i - dl] >= d) {
-            const ulonglong2 v = prefix_of(kb[i - dl], d);
-            alone = v.x != w.x || v.y != w.y;
-          }
-        }
-        if (alone) { keep = j + 1; break; }
+      for (int kk = 0; kk < 4; ++kk) {  // (the second and third event of the thread's four rows: one round of loads)
+        const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
+        ev1[kk] = 0; ev2[kk] = 0;
+        if (n_ev[kk] >= 3u) ev1[kk] = evs[0];
+        if (n_ev[kk] >= 4u) ev2[kk] = evs[1];
       }
-      n_ev[kk] = keep;
+      uint32_t listed = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) listed += n_ev[kk] >= 2u ? 1u : 0u;
+      uint32_t n_listed;
+      uint32_t at = team_excl_scan(listed, &n_listed);
+      bool too_many = false;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (n_ev[kk] < 2u) continue;
+        const uint32_t i = 4u * tid + (uint32_t)kk;
+        const uint64_t* evs = ix.chain_ev + (meta[kk] >> kChainEvOffShift);
+        uint64_t word = (uint64_t)i | ((uint64_t)n_ev[kk] << 10);
+        if (n_ev[kk] > 9u) { too_many = true; word = (uint64_t)i | (1ull << 10); }  // (the level-by-level kernel takes the read)
+        else
+          for (uint32_t j = 0; j + 1 < n_ev[kk]; ++j) {
+            const uint64_t e = j == 0 ? ev0[kk] : j == 1 ? ev1[kk] : j == 2 ? ev2[kk] : evs[j - 1];
+            word |= (e >> 58) << (16u + 6u * j);
+          }
+        pay[at++] = word;  // (pay and acc_of are not in use before the entries are made)
+      }
+      if (too_many) cnt[0] = 1u;
+      team_sync<T>();
+      SBWT_PHASE_MEM(5);
+      // eight threads per listed row: the sixteen nearest neighbours in one round of LDS reads, the next sixteen in the
+      // next (under load an LDS read takes hundreds of clocks: the neighbours one after the other were what was slow)
+      const uint32_t sub = tid & 7u;
+      for (uint32_t q2 = tid >> 3; q2 < n_listed; q2 += T >> 3) {
+        const uint64_t word = pay[q2];
+        const uint32_t i = (uint32_t)word & 1023u, n = (uint32_t)(word >> 10) & 63u;
+        const ulonglong2 mine = kb[i];
+        uint32_t keep = n;
+        for (uint32_t j = 0; j + 1 < n; ++j) {
+          const uint32_t d = (uint32_t)(word >> (16u + 6u * j)) & 63u;
+          if (d == 0) continue;  // (level 0, searcher.hpp:424-443, has no early return)
+          const ulonglong2 w = prefix_of(mine, d);
+          // (on an index that is k-ordered as far as the walk reaches there IS another chain through the node whenever this one
+          // has a later event -- a lone row would be a unique occurrence from here on -- and it is a row nearby: the copies
+          // the chain hops between share their right contexts too.  So: the neighbours first, and out at the first sharer.)
+          bool alone = true;
+          for (uint32_t first = 1; first < m && alone; first += 8u) {
+            const uint32_t dl = first + sub;
+            uint32_t share = 0;
+            if (dl < m) {
+              const uint32_t o1 = i + dl;
+              if (o1 < m && len_of[o1] >= d) {
+                const ulonglong2 v = prefix_of(kb[o1], d);
+                share = v.x == w.x && v.y == w.y ? 1u : 0u;
+              }
+              if (!share && i >= dl && len_of[i - dl] >= d) {
+                const ulonglong2 v = prefix_of(kb[i - dl], d);
+                share = v.x == w.x && v.y == w.y ? 1u : 0u;
+              }
+            }
+            share |= (uint32_t)__shfl_xor((int)share, 1);
+            share |= (uint32_t)__shfl_xor((int)share, 2);
+            share |= (uint32_t)__shfl_xor((int)share, 4);
+            alone = share == 0;
+          }
+          if (alone) { keep = j + 1; break; }
+        }
+        if (sub == 0) acc_of[i] = (uint16_t)keep;
+      }
+      team_sync<T>();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        if (n_ev[kk] >= 2u) n_ev[kk] = acc_of[4u * tid + (uint32_t)kk];
+      team_sync<T>();  // (pay and acc_of are written again below)
     }
-#ifdef SBWT_PHASE_CLOCKS
-    team_sync<T>();  // (so that the prune phase is the slowest thread's, not thread 0's)
-#endif
     SBWT_PHASE_MEM(1);
     // ---- entries: numbered thread by thread, i.e. in row order
     uint32_t H;
