@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void k_multi(const DeviceIndex ix, const MapAr
     if (r == kQueueDone) continue;  // k_multi_bfs took it
     const MultiRead res = rio_load(a.io, r);
     const uint64_t lo = res.lo, hi = res.hi;
+    if (hi <= lo) continue;  // (a record in a wide[] slot past wide_cap was never written: the batch fails with SBWT_ERR_CAPACITY)
     MultiState S;
     S.ix = &ix;
     S.out = a.hits + res.first_hit;

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256, kNodes > 512 ? 1 : 3) void k_multi_bfs(const D
     if (r == kQueueDone) continue;  // (team-uniform)
     const MultiRead res = rio_load(a.io, r);  // first_hit is global by now (k_multi_sort)
     const uint64_t lo = res.lo, m = res.hi - res.lo;
-    if (m > (T == 64 ? kNodes : kSortMax)) continue;
+    if (m == 0 || m > (T == 64 ? kNodes : kSortMax)) continue;  // (0 rows: a record past wide_cap, never written -- the batch fails)
     const uint32_t L = a.lens[r];
     team_sync<T>();  // the previous read is done with the team's LDS
     if (tid < 4) cnt[tid] = 0;
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, co
     if (r == kQueueDone) continue;  // (team-uniform)
     const MultiRead res = rio_load(a.io, r);  // first_hit is global by now (k_multi_sort)
     const uint64_t lo = res.lo, m64 = res.hi - res.lo;
-    if (m64 > kCap) continue;
+    if (m64 == 0 || m64 > kCap) continue;  // (0 rows: a record past wide_cap, never written -- the batch fails)
     const uint32_t m = (uint32_t)m64;
     const uint32_t L = a.lens[r];
     team_sync<T>();  // the previous read is done with the team's LDS

@@ -161,6 +161,16 @@ def make_reads(rng, codes, fams, chr_start, keys, n, l_max=512, wide=False):
     return out
 
 
+# the rare paths (tests/test_gpu_rare_paths.py), drawn from seed 300000 on: results that do not fit a 16-byte entry
+# (wide records, the ring bypass), the filter tables in global memory instead of LDS, host batches cut into sub-batches
+RARE_KNOBS = {
+    "SBWT_DEBUG_RING_WIDTH": [None, None, None, "0", "2", "40"],
+    "SBWT_DEBUG_RING_CHR": [None, None, None, "0"],
+    "SBWT_DEBUG_LDS_KEYS": [None, None, None, "0"],
+    "SBWT_SUBBATCH": [None, None, "128", "1024"],
+}
+
+
 def pick(rng, table):
     env = {}
     for k, choices in table.items():
@@ -225,6 +235,8 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
     g = len(codes)
     build_env = pick(rng, BUILD_KNOBS)
     pass_env = pick(rng, PASS_KNOBS)
+    if seed >= 300000:
+        pass_env.update(pick(rng, RARE_KNOBS))
     for k_, v_ in (override or {}).items():
         for env_ in (build_env, pass_env):
             env_.pop(k_, None)

@@ -17,7 +17,7 @@ def test_fuzz_seed(oracle, seed):
 
 
 @pytest.mark.parametrize("seed,lists_longer", [(34, True), (49, True), (110, True), (120, True), (37, False), (46, False),
-                                               (78, False), (143, False), (100610, True), (100643, True), (200100, False), (200101, False)])
+                                               (78, False), (143, False), (100610, True), (100643, True), (200100, False), (200101, False), (300222, False)])
 def test_fuzz_seed_beyond_the_sort_depth(oracle, seed, lists_longer):
     """Reads of L bases on an index whose suffix order stops before L + interval - 1 bases (upstream's builder stops at
     sort_len 256: reads of 194 bases and more).  Upstream's depth-first locate then reports a row every time its chain
@@ -25,7 +25,8 @@ def test_fuzz_seed_beyond_the_sort_depth(oracle, seed, lists_longer):
     over it), and a one-row interval whose first position the filters drop goes on to a second one (searcher.hpp:440 breaks
     the loop only).  The library reports the same lists: the longer ones in slots behind all others (seeds 34, 49, 110,
     120: through k_multi_chain, k_multi_bfs and k_multi), the one-row reads through the depth-first locate (the others;
-    each of these seeds failed before that)."""
+    each of these seeds failed before that).  Seed 300222: an index sampled every 128 rows, every result forced into wide[]
+    and wide[] too small at first -- k_multi met records that were never written (zero rows) and read out of bounds."""
     import sbwt_amd as sb
     import fuzz_parity
     sb.device_count()
