@@ -339,7 +339,7 @@ def cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores):
             "oracle_1_thread_sample": n1, "oracle_all_cores_reads_per_s": round(rn, 1), "cores": cores,
             "gpu_device_pass_reads_per_s": round(n / (ms * 1e-3), 1), "gpu_identical_to_oracle": same,
             "reference_binary_reads_per_s": {"-n 1": "3.4e4 - 4.1e4", "-n 8": 2.73e5,
-                                             "source": "BASELINE.md (survey container, other host; not measured here)"}}
+                                             "source": "BASELINE.md (other host)"}}
 
 
 class Workload:
@@ -899,7 +899,7 @@ def main():
     probe = {}
     for cpl in (1, 2, 4):
         rate, pbytes = ix.probe_random_access(chains_per_lane=cpl, chain_len=64, workgroups_per_cu=8)
-        probe["%d_chains_per_lane" % cpl] = round(rate / 1e9, 2)
+        probe["%d" % cpl] = round(rate / 1e9, 2)
     gather_peak = max(probe.values())
     # ... and the same gather with what a mapping kernel cannot avoid: the address of every line comes from a streamed
     # 16-byte record and a 16-byte result is written per line (no dependent chains, no other work)
@@ -919,7 +919,7 @@ def main():
             t = json.load(open(tpath))
             if t.get("reads") == n_reads and t.get("read_len") == L and abs(t.get("scale", 1.0) - args.scale) < 1e-9 and plain \
                     and not args.rank_path and t.get("kernel") == dom_kernel:
-                stored = {"source": "profiles/%s/traffic_%s.json: PMC passes of the same command on another box, NOT this run" % (tdir, args.layout),
+                stored = {"source": "profiles/%s/traffic_%s.json: PMC passes of the same command, another box, NOT this run" % (tdir, args.layout),
                           "traffic_GB_per_launch": t.get("traffic_GB_per_launch"),
                           "hbm_requests_per_launch": t.get("hbm_requests_per_launch")}
     roofline = {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -927,7 +927,7 @@ def main():
                 "launch_ms": round(dom_ms, 3), "algorithmic_GB_per_launch": round(algo_bytes / 1e9, 2),
                 "index_lines_per_read": round(accesses / n_reads, 3), "bytes_per_read": round(algo_bytes / n_reads, 1),
                 "index_lines_per_s_G": round(lines_per_s, 2),
-                "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-byte-line accesses/s",
+                "gather_roofline": {"measured_in_this_run": True, "unit": "G dependent random 128-B-line accesses/s",
                                     "table_GB": round(pbytes / 1e9, 1), "by_chains_per_lane": probe, "peak": gather_peak,
                                     "kernel_index_lines_frac": round(lines_per_s / gather_peak, 3),
                                     # independent random lines whose addresses come from a streamed 16-byte record, a 16-byte
@@ -969,7 +969,7 @@ def main():
         cpu = {"value": round(sample_n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
                "sample": "first %d reads of the same batch, same index (reference-format tables), %d threads; "
                          "single thread: %.0f reads/s on %d reads" % (sample_n, cores, rate1, probe_n),
-               "note": "about 2x the reference binary per thread (SURVEY.md section 6)"}
+               "note": "about 2x the reference binary per thread"}
         if not args.no_extras and args.min_len is None:
             # end to end, measured in this run (never `value`): (a) host buffers in, host buffers out through
             # page-locked memory (PCIe both ways), (b) FASTQ file -> SAM file with 16 host threads
@@ -1066,9 +1066,9 @@ def main():
             t1 = time.time()
             try:
                 out = fn()
-                for e in (out if isinstance(out, list) else [out]):
-                    e["s"] = round(time.time() - t1, 1)     # wall time of this entry, builds and checks included
-                    configs.append(e)
+                out = out if isinstance(out, list) else [out]
+                out[0]["s"] = round(time.time() - t1, 1)    # wall time of this name's entries, builds and checks included
+                configs.extend(out)
             except Exception as e:   # a side line must never cost the headline
                 configs.append({"name": name, "error": "%s: %s" % (type(e).__name__, e)})
                 torch.cuda.empty_cache()
@@ -1105,11 +1105,11 @@ def main():
         n_mid, n_small = n_reads // 5, n_reads // 10     # 2 x 10^7 and 10^7 in the full-size run
         fresh("config2_dm6", "configs[1]: dm6-sized index, %d x 36 bp" % n_small, n_small, 36, ["hits", "compact"], scale=0.0486 * args.scale)
         fresh("repeats", "40 %% of the genome in diverged repeat families, %d x 50 bp" % n_mid, n_mid, 50, ["hits"], probe_n=5000, genome="repeats")
-        fresh("repeats_shuffled_ties", "the same, suffix order stopped at sort_len 256 with ties shuffled (upstream's builder), %d x 50 bp" % n_mid,
+        fresh("repeats_shuffled_ties", "the same, suffix order stopped at sort_len 256, ties shuffled (upstream's builder), %d x 50 bp" % n_mid,
               n_mid, 50, ["hits"], probe_n=5000, genome="repeats", shuffle_ties=True)
         fresh("config5_smallrna", "configs[4] per GPU: planted 30-mer family, %d x 18..30 nt" % n_mid, n_mid, 30,
               ["hits"], probe_n=5000, min_len=18, plant=True)
-        fresh("rank_path", "no memoised search prefix (12-mer table + rank queries), %d x 50 bp" % n_reads, n_reads, 50,
+        fresh("rank_path", "no memoised prefix (12-mer table + rank queries), %d x 50 bp" % n_reads, n_reads, 50,
               ["compact"], rank_path=True)
         if run_cpu and not args.no_extras:
             try:
@@ -1125,6 +1125,8 @@ def main():
             wl.close()
             line["cpu_baseline_config1"] = cpu_config1(torch, dev, sbwt_amd, oracle_lib, cores)
         wl.close()
+    # (one line the driver keeps whole: counters that are zero on this workload say nothing)
+    line["detail"] = {k: v for k, v in line["detail"].items() if not (isinstance(v, int) and not isinstance(v, bool) and v == 0)}
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
