@@ -76,23 +76,74 @@ __global__ __launch_bounds__(256) void k_search_rounds(const DeviceIndex ix, con
   uint32_t wave_multi = 0;  // wave-uniform: how many such reads
   uint32_t tally = 0;       // index lines this lane read
 
+  // A batch runs as many rounds as its longest search needs, and a lane that is through idles (tried: refilling it at once
+  // -- every round type in every iteration cost more than it saved).  So the reads of a batch should need about the same
+  // number of rounds, and what says most about that is the length: the wave orders every 256 consecutive reads of its range
+  // by length (a counting sort over the lengths in steps of two, in LDS) and takes its batches from that order.  Batches of
+  // one length, as in a batch of fixed-length reads, stay what they were.
+  __shared__ uint32_t s_len_hist_all[4][64];
+  __shared__ uint16_t s_perm_all[4][256];
+  uint32_t* const s_len_hist = s_len_hist_all[threadIdx.x >> 6];
+  uint16_t* const s_perm = s_perm_all[threadIdx.x >> 6];
   uint4 rec = make_uint4(0, 0, 0, 0), rec2 = rec;
   uint32_t L = 0;
-  if (range_begin + lane < range_end) {
-    rec = recs[(range_begin + lane) * kPieces];
-    if (kLong) rec2 = recs[(range_begin + lane) * kPieces + 1];
-    L = a.lens[range_begin + lane];
-  }
   for (uint64_t base = range_begin; base < range_end; base += 64) {
-    const uint64_t r = base + lane;
-    const bool valid = r < range_end;
-    // the records of the next batch are on their way while this one is searched
+    const uint32_t in_group = (uint32_t)((base - range_begin) & 255u);     // 0, 64, 128, 192
+    const uint64_t group = base - in_group;
+    const uint32_t n_group = (uint32_t)(range_end - group < 256u ? range_end - group : 256u);
+    if (in_group == 0) {  // (wave-uniform) a new group of up to 256 reads: its order
+      s_len_hist[lane] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      uint32_t bkt[4], rnk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t x = lane + 64u * (uint32_t)k;
+        bkt[k] = 0; rnk[k] = 0;
+        if (x < n_group) {
+          const uint32_t len = a.lens[group + x];
+          bkt[k] = len >> 1 < 63u ? len >> 1 : 63u;
+          rnk[k] = atomicAdd(&s_len_hist[bkt[k]], 1u);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t mine = s_len_hist[lane];
+      uint32_t inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, d);
+        if ((int)lane >= d) inc += up;
+      }
+      __builtin_amdgcn_wave_barrier();
+      s_len_hist[lane] = inc - mine;  // first place of the bucket
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t x = lane + 64u * (uint32_t)k;
+        if (x < n_group) s_perm[s_len_hist[bkt[k]] + rnk[k]] = (uint16_t)x;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      rec = make_uint4(0, 0, 0, 0); rec2 = rec; L = 0;
+      if (lane < n_group) {
+        const uint64_t r0 = group + s_perm[lane];
+        rec = recs[r0 * kPieces];
+        if (kLong) rec2 = recs[r0 * kPieces + 1];
+        L = a.lens[r0];
+      }
+    }
+    const bool valid = in_group + lane < n_group;
+    const uint64_t r = valid ? group + s_perm[in_group + lane] : range_end;
+    // the records of the group's next batch are on their way while this one is searched
     uint4 nrec = make_uint4(0, 0, 0, 0), nrec2 = nrec;
     uint32_t nL = 0;
-    if (r + 64 < range_end) {
-      nrec = recs[(r + 64) * kPieces];
-      if (kLong) nrec2 = recs[(r + 64) * kPieces + 1];
-      nL = a.lens[r + 64];
+    if (in_group + 64u + lane < n_group) {
+      const uint64_t rn = group + s_perm[in_group + 64u + lane];
+      nrec = recs[rn * kPieces];
+      if (kLong) nrec2 = recs[rn * kPieces + 1];
+      nL = a.lens[rn];
     }
     const uint64_t w0 = u64_of(rec.x, rec.y), w1 = u64_of(rec.z, rec.w), w2 = u64_of(rec2.x, rec2.y), w3 = u64_of(rec2.z, rec2.w);
     auto word_of = [&](uint32_t jj) -> uint64_t {  // the 32-base word base jj lies in
