@@ -243,6 +243,10 @@ def run_seed(seed, sb, oracle, n_reads=12000, verbose=True, override=None, beyon
         if v_ is not None:
             (build_env if k_ in BUILD_KNOBS else pass_env)[k_] = v_
     interval = int(rng.choice([64, 64, 64, 64, 16, 32, 128, 256]))
+    if interval == 256 and pass_env.get("SBWT_SUBBATCH") == "128":
+        # (every multi-hit read of such an index takes the depth-first kernel, one lane per read: launches of 128 reads
+        # make a seed last minutes -- seed 301013: 196 s, green)
+        pass_env["SBWT_SUBBATCH"] = "1024"
     # The k-ordering contract: a suffix order stopped at k bases answers patterns of up to k bases exactly, and the
     # locate extends a read of L bases by up to interval - 1 more: L + interval - 1 <= k.  (Beyond it upstream's walk
     # reports rows twice or not at all; the library follows it up to the raw interval size and flags the rest
