@@ -73,7 +73,7 @@ struct Frame {  // one activation of find_possible
 struct MultiState {
   const DeviceIndex* ix;
   sbwt_hit* out;
-  uint64_t cap;    // slots reserved = raw interval size
+  uint64_t cap;    // room of the list: the slots reserved (raw interval size), or the list's own (extra_slots) on the second walk
   uint64_t nres;   // accepted pushes (VARS.result.size())
   uint32_t L;
   int strand;

@@ -529,7 +529,8 @@ __device__ unsigned long long g_multi_phase[24];  // [0..12) wave teams, [12..24
 //    size) compares a count that only grows: once it holds at the entry of a node it holds for every later node, so
 //    the list is cut at the first node boundary (in emission order) where the accepted hits before it equal the
 //    interval size -- and nowhere if the count jumps over that value inside one node;
-//  * pushes beyond the reserved slots set SBWT_RF_TRUNCATED (k_multi, MultiState).
+//  * a list longer than the interval has rows goes into slots of its own (extra_slots above); SBWT_RF_TRUNCATED only
+//    where the record cannot hold its length.
 // Teams are waves for reads of up to 64 rows (four per workgroup), workgroups up to kSortMax rows; a read whose
 // frontier or hits outgrow the team's LDS stays in the queue for k_multi.  A read done here leaves ~0 in its entry.
 constexpr uint32_t kQueueDone = ~0u;
@@ -1307,7 +1308,7 @@ __global__ __launch_bounds__(256, 3) void k_multi_sort(const DeviceIndex ix, con
 //    sorted by (first d bases of the chain, d), ties in row order (team_sort_rows; entries are numbered in row order);
 //  * a node of ONE row that is sampled has no children (searcher.hpp:495): an event at depth d >= 1 of a chain whose
 //    first d bases no other chain of the read shares (no other row passes through that node) ends the chain there;
-//  * the early exit (searcher.hpp:464) and SBWT_RF_TRUNCATED: as in k_multi_bfs, on the sorted list.
+//  * the early exit (searcher.hpp:464) and the lists longer than their intervals: as in k_multi_bfs, on the sorted list.
 // A read whose entries outgrow the team, or with a row chain_tab does not hold, stays queued for k_multi_bfs / k_multi.
 template <int T, bool kLds>
 __global__ __launch_bounds__(256, 3) void k_multi_chain(const DeviceIndex ix, const MultiSortArgs a, uint32_t* __restrict__ queue,
